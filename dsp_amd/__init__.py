@@ -1,0 +1,13 @@
+"""dsp_amd: MI355X (gfx950) FIR engine behind dsp::firwin -> dsp::lfilter(b, 1.0, x).
+
+Layout:
+  csrc/        HIP kernels (fir_kernels.hip) and the extern "C" ABI (dspx_capi.hip)
+  lib/         the built libdspx.so (in-tree, not tracked by git)
+  build.py     hipcc recipe
+  _lib.py      ctypes loader (raises if the library is missing; no CPU fallback)
+  api.py       numpy / torch marshalling for tests and the benchmark
+The C++ drop-in header is include/dsp.hpp; the C ABI is include/dspx.h.
+"""
+from ._lib import DspxError, lib  # noqa: F401
+from .api import (SEED, checksum, device_count, fill_splitmix, fir_device, firwin, lfilter,  # noqa: F401
+                  lfilter_multi)

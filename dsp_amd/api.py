@@ -1,0 +1,109 @@
+"""Python-side callers of the C ABI, for tests, the smoke check and the benchmark.
+
+The product's host language is C++ (include/dsp.hpp mirrors the reference's
+dsp::firwin / dsp::lfilter); these helpers only marshal numpy arrays and torch
+device tensors into the same extern "C" entry points.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import DSPX_FIR_EXACT, DSPX_FIR_FMA, check, lib
+
+SEED = 0x44535046495236
+
+
+def device_count() -> int:
+    return int(lib().dspx_device_count())
+
+
+def _flags(exact: bool) -> int:
+    return DSPX_FIR_EXACT if exact else DSPX_FIR_FMA
+
+
+def _np_f64(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def firwin(numtaps: int, cutoff, pass_zero: bool = True, scale: bool = True) -> np.ndarray:
+    """dsp::firwin through the library (host arithmetic, see include/dsp.hpp)."""
+    c = _np_f64(np.atleast_1d(cutoff))
+    out = np.empty(max(int(numtaps), 1), dtype=np.float64)
+    check(lib().dspx_firwin_f64(int(numtaps), c.ctypes.data, c.size, int(pass_zero), int(scale), out.ctypes.data))
+    return out[: int(numtaps)]
+
+
+def lfilter(b, x, exact: bool = False) -> np.ndarray:
+    """dsp::lfilter(b, 1.0, x) for host arrays: 1-D x, or 2-D (channels, samples)."""
+    b, x = _np_f64(b), _np_f64(x)
+    y = np.empty_like(x)
+    if x.ndim == 1:
+        check(lib().dspx_fir_f64(b.ctypes.data, b.size, x.ctypes.data, y.ctypes.data, x.size, _flags(exact)))
+    elif x.ndim == 2:
+        check(lib().dspx_fir_f64_batched(b.ctypes.data, b.size, x.ctypes.data, y.ctypes.data, x.shape[0], x.shape[1],
+                                         x.shape[1], _flags(exact)))
+    else:
+        raise ValueError("x must be 1-D or 2-D")
+    return y
+
+
+def lfilter_multi(b, x, ngpus: int = 0, exact: bool = False) -> np.ndarray:
+    b, x = _np_f64(b), _np_f64(x)
+    x2 = x.reshape(1, -1) if x.ndim == 1 else x
+    y = np.empty_like(x2)
+    check(lib().dspx_fir_f64_multi(b.ctypes.data, b.size, x2.ctypes.data, y.ctypes.data, x2.shape[0], x2.shape[1],
+                                   x2.shape[1], int(ngpus), _flags(exact)))
+    return y.reshape(x.shape)
+
+
+# ---- torch device tensors ----------------------------------------------------------
+
+def _stream_ptr():
+    import torch
+
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def fir_device(taps, x, out=None, hist=None, exact: bool = False):
+    """Filters a float64 CUDA tensor x of shape (n,) or (channels, n) with device taps.
+    `hist`, if given, has shape (..., ntaps-1): the samples preceding x along the last axis."""
+    import torch
+
+    assert x.is_cuda and x.dtype == torch.float64 and taps.is_cuda and taps.dtype == torch.float64
+    x2 = x.reshape(1, -1) if x.dim() == 1 else x
+    assert x2.dim() == 2 and x2.stride(1) == 1
+    if out is None:
+        out = torch.empty_like(x2, memory_format=torch.contiguous_format)
+    o2 = out.reshape(1, -1) if out.dim() == 1 else out
+    assert o2.shape == x2.shape and o2.stride(1) == 1
+    hptr, hstride = None, 0
+    if hist is not None:
+        h2 = hist.reshape(1, -1) if hist.dim() == 1 else hist
+        assert h2.is_cuda and h2.dtype == torch.float64 and h2.shape == (x2.shape[0], max(taps.numel() - 1, 0))
+        assert h2.stride(1) == 1 or h2.shape[1] <= 1
+        hptr, hstride = h2.data_ptr(), h2.stride(0)
+    check(lib().dspx_fir_f64_dev(taps.data_ptr(), taps.numel(), x2.data_ptr(), x2.stride(0), hptr, hstride,
+                                 o2.data_ptr(), o2.stride(0), x2.shape[0], x2.shape[1], _flags(exact), _stream_ptr()))
+    return out.reshape(x.shape) if out.dim() != x.dim() else out
+
+
+def fill_splitmix(t, seed: int = SEED, offset: int = 0):
+    """Fills a contiguous float64 CUDA tensor with the deterministic [-1, 1) sequence."""
+    import torch
+
+    assert t.is_cuda and t.dtype == torch.float64 and t.is_contiguous()
+    check(lib().dspx_fill_splitmix_f64_dev(t.data_ptr(), t.numel(), seed & (2**64 - 1), offset & (2**64 - 1),
+                                           _stream_ptr()))
+    return t
+
+
+def checksum(t, offset: int = 0) -> int:
+    import torch
+
+    assert t.is_cuda and t.dtype == torch.float64 and t.is_contiguous()
+    out = torch.zeros(1, dtype=torch.int64, device=t.device)
+    check(lib().dspx_checksum_f64_dev(t.data_ptr(), t.numel(), offset & (2**64 - 1), out.data_ptr(), _stream_ptr()))
+    return int(out.item()) & (2**64 - 1)

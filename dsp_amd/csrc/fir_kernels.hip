@@ -1,0 +1,284 @@
+// FP64 direct-form FIR kernels for gfx950 (MI355X).
+//
+// Computes y[i] = sum_j taps[j] * x[i-j] with taps ascending per output, i.e. the
+// inner loop of the reference lfilter (dsp.hpp:356-365) for a denominator of size 1,
+// with the samples before x[0] taken as zero (or from an explicit history buffer).
+//
+// Work decomposition
+//   * one workgroup (256 threads = 4 waves) produces a tile of 2048 consecutive
+//     outputs of one channel; thread t owns outputs 8t .. 8t+7 of the tile;
+//   * taps are consumed in stages of at most 256; per stage the workgroup copies the
+//     input window [tile_start - j0 - 256, tile_start - j0 + 2048) from HBM/L2 into LDS
+//     with coalesced 16-byte loads;
+//   * inside a stage a thread handles 16 taps at a time: it reads the 24 samples those
+//     taps touch from LDS (12 x ds_read_b128) and issues 128 v_fmac_f64 whose tap operand
+//     is an SGPR pair (scalar loads), so the VALU issues nothing but FMAs in the steady
+//     state; latency of the LDS and scalar loads is covered by the other resident waves;
+//   * accumulators go back through LDS so that the tile is stored with coalesced
+//     16-byte stores.
+//
+// LDS image: slot q of the window is stored at q + 2*(q/8) (two pad slots per 8 samples).
+// Thread t reads slots 8t + const, which the padding turns into a stride of 10 doubles
+// (80 bytes): 16-byte aligned for ds_read_b128 and conflict-free, because the 16 lanes
+// of a ds_read_b128 group start at 16 distinct multiples of 4 banks.
+#include <hip/hip_runtime.h>
+
+#include "fir_kernels.h"
+
+namespace dspx {
+
+namespace {
+
+constexpr int kBlock = 256;               // threads per workgroup
+constexpr int kR = 8;                     // outputs per thread
+constexpr int kGroup = 16;                // taps per unrolled group
+constexpr int kWin = kGroup + kR;         // samples a group reads per thread (23 needed, 24 loaded)
+constexpr int kTile = kBlock * kR;        // outputs per workgroup
+constexpr int kStageTaps = 256;           // taps per LDS stage
+constexpr int kHalo = kStageTaps;         // window slots in front of the tile
+constexpr int kSlots = kHalo + kTile;     // window slots per stage
+constexpr int kLdsDoubles = kSlots + kSlots / 4;
+constexpr int kStageIters = (kSlots / 2 + kBlock - 1) / kBlock;  // 16-byte loads per thread per stage
+
+static_assert(kR == 8 && kGroup == 16, "the window indexing below assumes 8 outputs per thread, 16-tap groups");
+static_assert(kHalo % 8 == 0 && kTile % 8 == 0 && kStageTaps % kGroup == 0, "padding groups must align");
+
+__device__ __forceinline__ int padded(int q) { return q + 2 * (q >> 3); }
+
+template <bool EXACT> __device__ __forceinline__ double mac(double b, double w, double acc) {
+    if constexpr (EXACT) {
+#pragma clang fp contract(off)
+        const double prod = b * w;
+        return acc + prod;
+    } else {
+        return __builtin_fma(b, w, acc);
+    }
+}
+
+// One input sample of a channel at signed position g: history (or zero) before the
+// channel start, zero past its end.
+__device__ __forceinline__ double sample_at(const double* __restrict__ xc, const double* __restrict__ hc,
+                                            long long g, long long n, int ntaps) {
+    if (g >= 0) return g < n ? xc[g] : 0.0;
+    if (hc != nullptr && g >= -(long long)(ntaps - 1)) return hc[(ntaps - 1) + g];
+    return 0.0;
+}
+
+// Loads the 24 samples that taps [16g, 16g+16) of a stage touch for one thread.
+// W[i] is the sample that tap 16g + t multiplies into output r when i = t - r + 7, i.e.
+// image slot kHalo - 16g + 8*tid + 7 - i.  `top` points at the slot of i = 0 for g = 0;
+// the slots of i = 8m .. 8m+7 are the 8 consecutive doubles that END at top - 10*(2g+m),
+// read here as four aligned 16-byte pairs.
+__device__ __forceinline__ void load_window(const double* top, int g, double (&W)[kWin]) {
+    const double* p = top - 20 * g;
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            const double2 v = *reinterpret_cast<const double2*>(p - 10 * m - 2 * h - 1);
+            W[8 * m + 2 * h] = v.y;
+            W[8 * m + 2 * h + 1] = v.x;
+        }
+    }
+}
+
+template <bool EXACT, bool VEC2>
+__global__ __launch_bounds__(kBlock) void fir_f64_kernel(const double* __restrict__ taps,
+                                                          const double* __restrict__ x,
+                                                          const double* __restrict__ hist, double* __restrict__ y,
+                                                          FirShape s) {
+    __shared__ __attribute__((aligned(16))) double lds[kLdsDoubles];
+    const int tid = threadIdx.x;
+
+    // Blocks b and b+8 share an XCD (and its L2): give every XCD a contiguous range
+    // of tiles so that neighbouring tiles find their shared halo in the same L2.
+    const unsigned long long b = blockIdx.x;
+    const unsigned long long q8 = s.total_tiles / 8, r8 = s.total_tiles % 8;
+    const unsigned long long grp = b % 8, k = b / 8;
+    const unsigned long long tile_id = (grp < r8 ? grp * (q8 + 1) : r8 * (q8 + 1) + (grp - r8) * q8) + k;
+
+    const unsigned long long chan = tile_id / s.tiles_per_chan;
+    const long long tile_start = (long long)(tile_id % s.tiles_per_chan) * kTile;
+    const double* __restrict__ xc = x + chan * s.x_stride;
+    const double* __restrict__ hc = hist ? hist + chan * s.hist_stride : nullptr;
+    const long long n = s.n;
+    const int ntaps = s.ntaps;
+
+    double acc[kR];
+#pragma unroll
+    for (int r = 0; r < kR; ++r) acc[r] = 0.0;
+
+    for (int j0 = 0; j0 < ntaps; j0 += kStageTaps) {
+        const int S = min(kStageTaps, ntaps - j0);
+        const int ngroups = S / kGroup;
+        const int rem = S % kGroup;
+
+        // ---- stage the window: slot q <- sample tile_start - j0 - kHalo + q ----
+        const long long g0 = tile_start - j0 - kHalo;
+        // lowest slot the window loads of this stage touch (whole 16-tap groups, a multiple of 8)
+        const int qlo = kHalo - kGroup * (ngroups + (rem ? 1 : 0));
+        if (j0 > 0) __syncthreads();  // readers of the previous stage are done
+        double v0[kStageIters], v1[kStageIters];
+        if (g0 + qlo >= 0 && g0 + kSlots <= n) {  // interior tile (workgroup-uniform): no edge tests
+#pragma unroll
+            for (int i = 0; i < kStageIters; ++i) {
+                const int q = qlo + 2 * (tid + i * kBlock);
+                v0[i] = 0.0, v1[i] = 0.0;
+                if (q < kSlots) {
+                    if constexpr (VEC2) {
+                        const double2 v = *reinterpret_cast<const double2*>(xc + (g0 + q));
+                        v0[i] = v.x, v1[i] = v.y;
+                    } else {
+                        v0[i] = xc[g0 + q], v1[i] = xc[g0 + q + 1];
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < kStageIters; ++i) {
+                const int q = qlo + 2 * (tid + i * kBlock);
+                v0[i] = 0.0, v1[i] = 0.0;
+                if (q < kSlots) {
+                    v0[i] = sample_at(xc, hc, g0 + q, n, ntaps);
+                    v1[i] = sample_at(xc, hc, g0 + q + 1, n, ntaps);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < kStageIters; ++i) {
+            const int q = qlo + 2 * (tid + i * kBlock);
+            if (q < kSlots)  // q is even: q and q+1 share a padding group and a 16-byte slot
+                *reinterpret_cast<double2*>(lds + padded(q)) = make_double2(v0[i], v1[i]);
+        }
+        __syncthreads();
+
+        // ---- accumulate the stage's taps, 16 per group ----
+        const double* __restrict__ tp = taps + j0;
+        const double* top = lds + padded(kHalo + 8 * tid + 7);
+        for (int g = 0; g < ngroups; ++g) {
+            double W[kWin], bt[kGroup];
+            load_window(top, g, W);
+#pragma unroll
+            for (int t = 0; t < kGroup; ++t) bt[t] = tp[g * kGroup + t];
+#pragma unroll
+            for (int t = 0; t < kGroup; ++t) {
+#pragma unroll
+                for (int r = 0; r < kR; ++r) acc[r] = mac<EXACT>(bt[t], W[t - r + 7], acc[r]);
+            }
+        }
+        if (rem) {  // last, partial group: taps predicated (wave-uniform branches)
+            double W[kWin], bt[kGroup - 1];
+            load_window(top, ngroups, W);
+#pragma unroll
+            for (int t = 0; t < kGroup - 1; ++t) bt[t] = tp[min(ngroups * kGroup + t, S - 1)];
+            // keep all scalar tap loads here, ahead of the branches (one wait instead of one per tap)
+#pragma unroll
+            for (int t = 0; t < kGroup - 1; ++t) asm volatile("" : "+s"(bt[t]));
+#pragma unroll
+            for (int t = 0; t < kGroup - 1; ++t) {
+                if (t < rem) {
+#pragma unroll
+                    for (int r = 0; r < kR; ++r) acc[r] = mac<EXACT>(bt[t], W[t - r + 7], acc[r]);
+                }
+            }
+        }
+    }
+
+    // ---- store the tile: accumulators -> LDS (stride 10) -> coalesced 16-byte stores ----
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < kR; r += 2)
+        *reinterpret_cast<double2*>(lds + padded(8 * tid + r)) = make_double2(acc[r], acc[r + 1]);
+    __syncthreads();
+    double* __restrict__ yc = y + chan * s.y_stride;
+#pragma unroll
+    for (int i = 0; i < kTile / 2 / kBlock; ++i) {
+        const int q = 2 * (tid + i * kBlock);
+        const long long g = tile_start + q;
+        const double2 o = *reinterpret_cast<const double2*>(lds + padded(q));
+        if (g + 1 < n) {
+            if constexpr (VEC2) {
+                *reinterpret_cast<double2*>(yc + g) = o;
+            } else {
+                yc[g] = o.x, yc[g + 1] = o.y;
+            }
+        } else if (g < n) {
+            yc[g] = o.x;
+        }
+    }
+}
+
+// SplitMix64 finaliser.
+__device__ __forceinline__ unsigned long long mix64(unsigned long long z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+constexpr unsigned long long kGamma = 0x9E3779B97F4A7C15ull;
+
+__global__ __launch_bounds__(256) void fill_splitmix_kernel(double* __restrict__ x, unsigned long long n,
+                                                            unsigned long long seed, unsigned long long offset) {
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const unsigned long long bits = mix64(seed + (offset + i + 1) * kGamma) >> 11;
+        x[i] = (double)bits * 0x1.0p-52 - 1.0;
+    }
+}
+
+__global__ __launch_bounds__(256) void checksum_kernel(const double* __restrict__ yv, unsigned long long n,
+                                                       unsigned long long offset, unsigned long long* __restrict__ out) {
+    __shared__ unsigned long long part[4];
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    unsigned long long acc = 0;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        acc += mix64((unsigned long long)__double_as_longlong(yv[i]) + (offset + i + 1) * kGamma);
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) acc += __shfl_down(acc, d, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, part[0] + part[1] + part[2] + part[3]);
+}
+
+}  // namespace
+
+int fir_tile() { return kTile; }
+
+hipError_t launch_fir_f64(const double* taps, const double* x, const double* hist, double* y, const FirShape& shape,
+                          bool exact, bool vec2, hipStream_t stream) {
+    if (shape.total_tiles == 0) return hipSuccess;
+    const dim3 grid((unsigned)shape.total_tiles), block(kBlock);
+    if (exact) {
+        if (vec2)
+            hipLaunchKernelGGL((fir_f64_kernel<true, true>), grid, block, 0, stream, taps, x, hist, y, shape);
+        else
+            hipLaunchKernelGGL((fir_f64_kernel<true, false>), grid, block, 0, stream, taps, x, hist, y, shape);
+    } else {
+        if (vec2)
+            hipLaunchKernelGGL((fir_f64_kernel<false, true>), grid, block, 0, stream, taps, x, hist, y, shape);
+        else
+            hipLaunchKernelGGL((fir_f64_kernel<false, false>), grid, block, 0, stream, taps, x, hist, y, shape);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_fill_splitmix(double* x, unsigned long long n, unsigned long long seed, unsigned long long offset,
+                                hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    const unsigned long long want = (n + 255) / 256;
+    const unsigned grid = (unsigned)(want < 65536ull ? want : 65536ull);
+    hipLaunchKernelGGL(fill_splitmix_kernel, dim3(grid), dim3(256), 0, stream, x, n, seed, offset);
+    return hipGetLastError();
+}
+
+hipError_t launch_checksum(const double* yv, unsigned long long n, unsigned long long offset, unsigned long long* out,
+                           hipStream_t stream) {
+    hipError_t e = hipMemsetAsync(out, 0, sizeof(unsigned long long), stream);
+    if (e != hipSuccess || n == 0) return e;
+    const unsigned long long want = (n + 255) / 256;
+    const unsigned grid = (unsigned)(want < 8192ull ? want : 8192ull);
+    hipLaunchKernelGGL(checksum_kernel, dim3(grid), dim3(256), 0, stream, yv, n, offset, out);
+    return hipGetLastError();
+}
+
+}  // namespace dspx

@@ -1,0 +1,246 @@
+// dsp.hpp — MI355X drop-in for the FIR path of Unbinilium/DSP.
+//
+// Same namespace, names, template parameters, defaults and error behaviour as the
+// reference header for:
+//     dsp::firwin        (reference dsp/include/dsp.hpp:190-311)   host tap design
+//     dsp::lfilter       (reference dsp.hpp:333-396)               FIR filtering on the GPU
+// plus what they depend on: dsp::constants (dsp.hpp:34-53), dsp::math::sinc
+// (dsp.hpp:60-67), dsp::hamming_window (dsp.hpp:74-115), dsp::types::window_t
+// (dsp.hpp:119-121), dsp::lfilter_ctx_t (dsp.hpp:333).
+//
+// Tap design runs on the host and performs the same IEEE-754 operations in the same
+// order as the reference, so the taps are bit-identical.  lfilter hands contiguous
+// double buffers to the C ABI in dspx.h (libdspx.so, hand-written gfx950 kernels).
+// There is no CPU filtering path in this header: a failing GPU call throws
+// std::runtime_error, and inputs the GPU path does not cover are rejected
+//   - at compile time when T or a container's value_type is not double,
+//   - with std::invalid_argument when the denominator has more than one
+//     coefficient (an IIR recurrence; reference dsp.hpp:366-368).
+//
+// Requires C++20.  Link with -ldspx.
+#pragma once
+
+#include <array>
+#include <cmath>
+#include <concepts>
+#include <cstddef>
+#include <iterator>
+#include <stdexcept>
+#include <string>
+#include <type_traits>
+#include <vector>
+
+#include "dspx.h"
+
+namespace dsp {
+
+namespace constants {
+
+inline constexpr double EPS = 1.0e-20;
+inline constexpr double PI = 3.14159265358979323846264338327950288419716939937510582097494459231;
+inline constexpr double SQRT_2 = 1.41421356237309504880168872420969807856967187537694807317667973799;
+inline constexpr double SQRT_2PI = 2.50662827463100050241576528481104525300698674060993831662992357634;
+
+}  // namespace constants
+
+using namespace constants;
+
+namespace math {
+
+// sin(pi x) / (pi x); arguments closer to zero than eps are moved to eps first.
+template <std::floating_point T> constexpr T sinc(T x, T eps = static_cast<T>(EPS)) {
+    const T arg = (std::abs(x) < eps ? eps : x) * static_cast<T>(PI);
+    return static_cast<T>(std::sin(arg) / arg);
+}
+
+}  // namespace math
+
+using namespace math;
+
+namespace types {
+
+enum class window_t {
+    HAMMING,
+};
+
+}  // namespace types
+
+using namespace types;
+
+namespace traits {
+
+// A container the design / filter functions accept: size() -> size_t, operator[],
+// and elements that convert to T without throwing.
+template <typename C, typename T>
+concept indexable_of = requires(const C& c, std::size_t i) {
+    { c.size() } -> std::same_as<std::size_t>;
+    c[i];
+    typename C::value_type;
+} && std::is_nothrow_convertible_v<typename C::value_type, T>;
+
+template <typename C, typename T>
+concept iterable_of = requires(const C& c) {
+    { c.size() } -> std::same_as<std::size_t>;
+    typename C::iterator;
+    typename C::const_iterator;
+    typename C::value_type;
+    c.begin();
+    c.end();
+} && std::is_nothrow_convertible_v<typename C::value_type, T>;
+
+template <typename C>
+concept contiguous_doubles = requires(const C& c) {
+    { std::data(c) } -> std::convertible_to<const double*>;
+} && std::contiguous_iterator<decltype(std::begin(std::declval<const C&>()))>;
+
+}  // namespace traits
+
+using namespace traits;
+
+// Generalised Hamming window  w[n] = alpha + (1 - alpha) cos(f_n),  f_n on a uniform grid
+// over [-pi, pi]: `width` points when sym, else the first `width` of width + 1 points.
+template <std::floating_point T> std::vector<T> hamming_window(std::size_t width, T alpha = static_cast<T>(0.54), bool sym = true) {
+    if (width < 2) [[unlikely]] throw std::invalid_argument("The width must be greater than or equal to 2.");
+    const std::size_t points = sym ? width : width + 1;
+    const T first = -PI;
+    const T span = std::abs(static_cast<T>(PI) - first);
+    const T last_index = points - 1;
+    const T coeff[2] = {alpha, static_cast<T>(static_cast<T>(1.0) - alpha)};
+    std::vector<T> w(width);
+    int n = 0;
+    for (auto& wn : w) {
+        const T f = first + (span * (static_cast<T>(n++) / last_index));
+        T v = static_cast<T>(0.0);
+        for (std::size_t k = 0; k < 2; ++k) v += coeff[k] * std::cos(static_cast<T>(k) * f);
+        wn = v;
+    }
+    return w;
+}
+
+// Windowed-sinc FIR design.  `cutoffs` are band edges in units of the Nyquist frequency.
+// As in the reference, when several band pairs are given only the last pair shapes the
+// taps (each pair overwrites the previous one), and the pass band used for scaling is
+// the first pair.
+template <typename T = double, typename Container>
+    requires iterable_of<Container, T>
+std::vector<T> firwin(std::size_t numtaps, const Container& cutoffs, bool pass_zero = true, bool scale = true,
+                      window_t window = window_t::HAMMING) {
+    if (cutoffs.size() == 0) [[unlikely]] throw std::invalid_argument("At least one cutoffs frequency must be given.");
+    const bool pass_nyquist = !pass_zero;
+    if (pass_nyquist && (numtaps % 2 == 0)) [[unlikely]]
+        throw std::invalid_argument("The number of numtaps must be odd when pass_nyquist is true.");
+    if (window != window_t::HAMMING) [[unlikely]] throw std::invalid_argument("Unsupported window type.");
+
+    std::vector<T> edges;
+    edges.reserve(cutoffs.size() + 2);
+    if (pass_zero) edges.push_back(static_cast<T>(0.0));
+    for (const auto& c : cutoffs) edges.push_back(static_cast<T>(c));
+    if (pass_nyquist) edges.push_back(static_cast<T>(1.0));
+
+    const T centre = static_cast<T>(0.5) * static_cast<T>(numtaps - 1);
+    const auto offset = [centre](std::size_t i) { return static_cast<T>(i) - centre; };
+
+    std::vector<T> h(numtaps, static_cast<T>(0.0));
+    if (edges.size() >= 2) {
+        const std::size_t hi = (edges.size() % 2 == 0) ? edges.size() - 1 : edges.size() - 2;  // last odd index
+        const T left = edges[hi - 1], right = edges[hi];
+        for (std::size_t j = 0; j < numtaps; ++j) {
+            const T m = offset(j);
+            h[j] = (right * sinc(right * m)) - (left * sinc(left * m));
+        }
+    }
+
+    const std::vector<T> win = hamming_window<T>(numtaps);
+    for (std::size_t i = 0; i < numtaps; ++i) h[i] *= win[i];
+
+    if (scale) {
+        const T left = edges[0], right = edges[1];
+        T f0;
+        if (left == static_cast<T>(0.0))
+            f0 = 0.0;
+        else if (right == static_cast<T>(1.0))
+            f0 = 1.0;
+        else
+            f0 = static_cast<T>(0.5) * (left + right);
+        T gain = 0.0;
+        for (std::size_t i = 0; i < numtaps; ++i) gain += h[i] * std::cos(static_cast<T>(PI) * offset(i) * f0);
+        if (std::abs(gain) < static_cast<T>(EPS)) [[unlikely]] gain = EPS;
+        for (auto& tap : h) tap /= gain;
+    }
+    return h;
+}
+
+template <std::floating_point T = double>
+std::vector<T> firwin(std::size_t numtaps, T cutoff, bool pass_zero = true, bool scale = true,
+                      window_t window = window_t::HAMMING) {
+    return firwin<T>(numtaps, std::array<T, 1>{cutoff}, pass_zero, scale, window);
+}
+
+template <typename T = double> struct lfilter_ctx_t { std::vector<T> result; };
+
+namespace detail {
+
+// Contiguous view of a container of doubles; copies only when the container is not
+// contiguous in memory (e.g. std::deque).
+template <typename C> class double_view {
+  public:
+    explicit double_view(const C& c) : size_(c.size()) {
+        if constexpr (contiguous_doubles<C>) {
+            data_ = std::data(c);
+        } else {
+            copy_.resize(size_);
+            for (std::size_t i = 0; i < size_; ++i) copy_[i] = c[i];
+            data_ = copy_.data();
+        }
+    }
+    const double* data() const { return data_; }
+    std::size_t size() const { return size_; }
+
+  private:
+    std::vector<double> copy_;
+    const double* data_ = nullptr;
+    std::size_t size_;
+};
+
+}  // namespace detail
+
+// y = lfilter(numerators, denominators, x) with zero initial state, written to ctx.result
+// (resized only when its length differs from x's).  denominators[0] is never read.
+template <typename T = double, typename Container_1, typename Container_2, typename Container_3>
+    requires std::floating_point<T> && indexable_of<Container_1, T> && indexable_of<Container_2, T> &&
+             indexable_of<Container_3, T>
+void lfilter(lfilter_ctx_t<T>& ctx, const Container_1& numerators, const Container_2& denominators,
+             const Container_3& x) {
+    static_assert(std::is_same_v<T, double> && std::is_same_v<typename Container_1::value_type, double> &&
+                    std::is_same_v<typename Container_2::value_type, double> &&
+                    std::is_same_v<typename Container_3::value_type, double>,
+                  "dsp::lfilter (MI355X): only T = double over containers of double is implemented");
+    if (denominators.size() > 1)
+        throw std::invalid_argument("dsp::lfilter (MI355X): denominators.size() > 1 (IIR) is not implemented");
+    const std::size_t n = x.size();
+    if (ctx.result.size() != n) [[unlikely]] ctx.result.resize(n);
+    if (n == 0) return;
+    const detail::double_view<Container_1> b(numerators);
+    const detail::double_view<Container_3> in(x);
+    const int rc = dspx_fir_f64(b.data(), b.size(), in.data(), ctx.result.data(), n, DSPX_FIR_FMA);
+    if (rc != DSPX_OK)
+        throw std::runtime_error(std::string("dsp::lfilter (MI355X): ") + dspx_status_string(rc) + ": " +
+                                 dspx_last_error());
+}
+
+template <typename T = double, typename Container_1, typename Container_2, typename Container_3>
+    requires std::floating_point<T> && indexable_of<Container_1, T> && indexable_of<Container_2, T> &&
+             indexable_of<Container_3, T>
+std::vector<T> lfilter(const Container_1& numerators, const Container_2& denominators, const Container_3& x) {
+    lfilter_ctx_t<T> ctx;
+    lfilter<T>(ctx, numerators, denominators, x);
+    return std::move(ctx.result);
+}
+
+template <typename T = double, typename Container_1, typename Container_2>
+    requires std::floating_point<T> && indexable_of<Container_1, T> && indexable_of<Container_2, T>
+std::vector<T> lfilter(const Container_1& numerators, T denominator, const Container_2& x) {
+    return lfilter<T>(numerators, std::array<T, 1>{denominator}, x);
+}
+
+}  // namespace dsp

@@ -1,0 +1,107 @@
+/*
+ * dspx — C ABI of the MI355X (gfx950) FIR engine behind dsp::lfilter(b, 1.0, x).
+ *
+ * The reference library (Unbinilium/DSP, dsp/include/dsp.hpp) is a header-only C++
+ * template library with no FFI of its own; the interface this ABI replaces is the
+ * body of its lfilter template.  Each entry point cites the reference lines whose
+ * behaviour it reproduces.  Plain pointers and sizes only; `stream` arguments are a
+ * hipStream_t passed as void* (NULL = the default stream).
+ *
+ * All functions return DSPX_OK (0) or a negative dspx_status; dspx_last_error()
+ * gives a thread-local message for the most recent failure on the calling thread.
+ * The entry points may be called concurrently from several host threads.
+ */
+#ifndef DSPX_H
+#define DSPX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#if defined(__GNUC__)
+#define DSPX_API __attribute__((visibility("default")))
+#else
+#define DSPX_API
+#endif
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum dspx_status {
+    DSPX_OK = 0,
+    DSPX_ERR_INVALID = -1,   /* bad pointer / size / stride / overlapping buffers */
+    DSPX_ERR_NO_DEVICE = -2, /* no usable gfx950 device */
+    DSPX_ERR_HIP = -3,       /* a HIP runtime call failed; see dspx_last_error() */
+    DSPX_ERR_NOMEM = -4      /* device allocation failed */
+} dspx_status;
+
+/* Arithmetic mode of the filter kernels (the `flags` argument). */
+#define DSPX_FIR_FMA 0u   /* default: one fused multiply-add per tap, taps ascending        */
+#define DSPX_FIR_EXACT 1u /* separately rounded multiply then add per tap, taps ascending:
+                             bit-identical to the reference loop compiled without FMA
+                             contraction (dsp.hpp:361-364); half the arithmetic rate        */
+
+DSPX_API int dspx_version(void);
+/* Number of visible HIP devices (0 if none or the runtime is unusable). */
+DSPX_API int dspx_device_count(void);
+DSPX_API const char* dspx_last_error(void);
+DSPX_API const char* dspx_status_string(int status);
+
+/* ---- host tap design (no GPU work) -------------------------------------------------
+ * C entry points into the library's own instantiation of the header templates in
+ * dsp.hpp, so that non-C++ callers get taps that are bit-identical to
+ *   firwin<double>(numtaps, cutoffs, pass_zero, scale, HAMMING)   dsp.hpp:190-304
+ *   hamming_window<double>(width, alpha, sym)                      dsp.hpp:74-115
+ *   sinc<double>(x)                                                dsp.hpp:60-67
+ * Arguments the reference throws std::invalid_argument for return DSPX_ERR_INVALID
+ * with the reference's message in dspx_last_error().  `out` holds numtaps / width doubles. */
+DSPX_API int dspx_firwin_f64(size_t numtaps, const double* cutoffs, size_t ncutoffs, int pass_zero, int scale,
+                             double* out);
+DSPX_API int dspx_hamming_window_f64(size_t width, double alpha, int sym, double* out);
+DSPX_API double dspx_sinc_f64(double x);
+
+/* ---- host-pointer entry points --------------------------------------------------
+ * y[i] = sum_{j < min(ntaps, i+1)} taps[j] * x[i-j], taps ascending, zero initial
+ * state, output length == input length: the FIR branch (denominator of size 1) of
+ *   lfilter(ctx, numerators, denominators, x)            dsp.hpp:342-371
+ * reached through lfilter(b, T den, x)                    dsp.hpp:393-396
+ * (the value of `den` is never read by the reference, dsp.hpp:366).
+ * n == 0 is a no-op; ntaps == 0 writes zeros (the reference's inner loop never runs).
+ * x and y must not overlap.  Runs on the current HIP device. */
+DSPX_API int dspx_fir_f64(const double* taps, size_t ntaps, const double* x, double* y, size_t n, unsigned flags);
+
+/* nchan independent channels (one reference lfilter call each), channel c at
+ * x + c*stride / y + c*stride, stride >= n, all with the same taps. */
+DSPX_API int dspx_fir_f64_batched(const double* taps, size_t ntaps, const double* x, double* y, size_t nchan, size_t n,
+                         size_t stride, unsigned flags);
+
+/* Same contract, sharded over the first `ngpus` devices (0 = all): contiguous channel
+ * ranges when nchan >= ngpus, otherwise contiguous segments of each channel with the
+ * preceding ntaps-1 input samples as history.  No inter-device exchange; results are
+ * bit-identical for every ngpus.  One host thread and stream per device. */
+DSPX_API int dspx_fir_f64_multi(const double* taps, size_t ntaps, const double* x, double* y, size_t nchan, size_t n,
+                       size_t stride, int ngpus, unsigned flags);
+
+/* ---- device-resident entry point ------------------------------------------------
+ * All pointers are device pointers on the current device; the launch is asynchronous
+ * on `stream`.  d_hist, when non-NULL, holds for every channel c the ntaps-1 samples
+ * that precede d_x[c*x_stride] (d_hist[c*hist_stride + ntaps-2] is x[-1]); NULL is the
+ * reference's zero initial state.  History has no counterpart in the reference (its
+ * lfilter keeps no state, dsp.hpp:356-365); it is what makes segment sharding and
+ * chunked streaming produce the same samples as one long call. */
+DSPX_API int dspx_fir_f64_dev(const double* d_taps, size_t ntaps, const double* d_x, size_t x_stride, const double* d_hist,
+                     size_t hist_stride, double* d_y, size_t y_stride, size_t nchan, size_t n, unsigned flags,
+                     void* stream);
+
+/* ---- deterministic synthetic data and checksums (benchmark / parity support) -----
+ * d_x[i] = ((mix64(seed + (offset+i+1)*0x9E3779B97F4A7C15) >> 11) * 2^-52) - 1.0,
+ * mix64 = the SplitMix64 finaliser; uniform in [-1, 1), exactly representable. */
+DSPX_API int dspx_fill_splitmix_f64_dev(double* d_x, size_t n, uint64_t seed, uint64_t offset, void* stream);
+/* *d_sum (device uint64, overwritten) = wrapping sum over i of
+ * mix64(bits(d_y[i]) + (offset+i+1)*0x9E3779B97F4A7C15).  Partition-independent. */
+DSPX_API int dspx_checksum_f64_dev(const double* d_y, size_t n, uint64_t offset, uint64_t* d_sum, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DSPX_H */

@@ -1,0 +1,205 @@
+"""GPU parity tests: every call goes through the C ABI in libdspx.so (ctypes), and is
+checked against the CPU oracle, the committed reference outputs and the literals of the
+reference's own tests.
+
+Parity bar (north_star): max|y - y_ref| / max|y_ref| <= 1e-12 for the default FMA mode
+(the only difference from the reference is one rounding per tap instead of two);
+bit-for-bit for DSPX_FIR_EXACT.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import scaled_err
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-12
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+@pytest.fixture(scope="module")
+def dsp():
+    import dsp_amd
+
+    assert dsp_amd.device_count() >= 1, "no MI355X visible"
+    return dsp_amd
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch
+
+    assert torch.cuda.is_available()
+    return torch
+
+
+# ---- the reference's own known-answer tests, through the GPU path ----
+
+def test_reference_test_lfilter_literals(dsp, literals):
+    t = literals["lfilter"]
+    w = dsp.firwin(t["numtaps"], t["cutoff"])
+    assert np.max(np.abs(w - np.array(literals["firwin"]["expected"]))) < literals["firwin"]["tol"]
+    y = dsp.lfilter(w, t["data"])
+    assert np.max(np.abs(y - np.array(t["expected"]))) < t["tol"]          # dsp.hpp:1583-1588, 1e-15 abs
+    y = dsp.lfilter(w, t["data"], exact=True)
+    assert np.max(np.abs(y - np.array(t["expected"]))) < t["tol"]
+
+
+def test_readme_example(dsp, golden):
+    w = dsp.firwin(100, 0.5)
+    assert np.array_equal(bits(w), bits(golden["taps_100_0p5"]))
+    y = dsp.lfilter(w, golden["readme_x"])
+    assert scaled_err(y, golden["readme_y"]) <= TOL
+    assert np.array_equal(bits(dsp.lfilter(w, golden["readme_x"], exact=True)), bits(golden["readme_y"]))
+
+
+@pytest.mark.parametrize("key", ["taps_101_0p25", "taps_255_0p25", "taps_4095_0p1"])
+def test_seeded_windows_vs_reference_outputs(dsp, oracle, golden, key):
+    x = oracle.fill_splitmix(1 << 14, dsp.SEED, 0)
+    ref = golden["seeded_y_" + key]
+    assert scaled_err(dsp.lfilter(golden[key], x), ref) <= TOL
+    assert np.array_equal(bits(dsp.lfilter(golden[key], x, exact=True)), bits(ref))
+
+
+def test_ragged_and_short_vs_reference_outputs(dsp, oracle, golden):
+    x = oracle.fill_splitmix(1000, dsp.SEED, 12345)
+    assert np.array_equal(bits(dsp.lfilter(golden["taps_255_0p25"], x[:777], exact=True)), bits(golden["ragged_y_255"]))
+    assert np.array_equal(bits(dsp.lfilter(golden["taps_4095_0p1"], x, exact=True)), bits(golden["short_y_4095"]))
+    assert scaled_err(dsp.lfilter(golden["taps_4095_0p1"], x), golden["short_y_4095"]) <= TOL
+
+
+# ---- tap-count and length sweeps against the oracle ----
+
+@pytest.mark.parametrize("ntaps", [1, 2, 7, 8, 15, 16, 17, 31, 32, 33, 100, 255, 256, 257, 300, 511, 512, 513, 1041])
+def test_tap_count_sweep(dsp, oracle, ntaps):
+    rng = np.random.default_rng(ntaps)
+    b = rng.standard_normal(ntaps)
+    for n in (1, 2, 63, 2047, 2048, 2049, 5000):
+        x = rng.standard_normal(n)
+        ref = oracle.lfilter(b, [1.0], x)
+        assert np.array_equal(bits(dsp.lfilter(b, x, exact=True)), bits(ref)), (ntaps, n)
+        assert scaled_err(dsp.lfilter(b, x), ref) <= TOL, (ntaps, n)
+
+
+def test_empty_inputs(dsp):
+    b = np.ones(5)
+    assert dsp.lfilter(b, np.zeros(0)).size == 0                       # empty x -> empty y (no error)
+    y = dsp.lfilter(np.zeros(0), np.arange(10.0))
+    assert y.shape == (10,) and np.all(y == 0.0)                       # no numerators -> zeros
+    assert dsp.lfilter(b, np.zeros((0, 8))).shape == (0, 8)
+    assert dsp.lfilter(b, np.zeros((3, 0))).shape == (3, 0)
+
+
+def test_invalid_arguments(dsp):
+    L = dsp.lib()
+    x = np.zeros(16)
+    b = np.ones(3)
+    assert L.dspx_fir_f64(b.ctypes.data, 3, x.ctypes.data, x.ctypes.data, 16, 0) == -1       # x and y overlap
+    assert L.dspx_fir_f64(None, 3, x.ctypes.data, x.ctypes.data, 16, 0) == -1                # NULL taps
+    y = np.zeros(16)
+    assert L.dspx_fir_f64(b.ctypes.data, 3, x.ctypes.data, y.ctypes.data, 16, 0x80) == -1    # unknown flag
+    assert L.dspx_fir_f64_batched(b.ctypes.data, 3, x.ctypes.data, y.ctypes.data, 2, 8, 4, 0) == -1  # stride < n
+    assert b"stride" in L.dspx_last_error()
+
+
+def test_unaligned_host_and_device_pointers(dsp, oracle, torch):
+    """8-byte (not 16-byte) aligned buffers take the scalar load/store variant."""
+    b = oracle.firwin(33, [0.3])
+    x = oracle.fill_splitmix(6001, 5, 0)
+    ref = oracle.lfilter(b, [1.0], x)
+    taps = torch.from_numpy(b).cuda()
+    big = torch.zeros(6002 * 2, dtype=torch.float64, device="cuda")
+    xin = big[1:6002]
+    xin.copy_(torch.from_numpy(x))
+    out = big[6002 + 1: 6002 + 6002]
+    assert xin.data_ptr() % 16 == 8 and out.data_ptr() % 16 == 8
+    dsp.fir_device(taps, xin, out=out, exact=True)
+    assert np.array_equal(bits(out.cpu().numpy()), bits(ref))
+    dsp.fir_device(taps, xin, out=out)
+    assert scaled_err(out.cpu().numpy(), ref) <= TOL
+
+
+def test_batched_channels_with_stride(dsp, oracle, torch):
+    nchan, n, stride = 5, 3001, 3008
+    b = oracle.firwin(101, [0.25])
+    x = np.zeros((nchan, stride))
+    for c in range(nchan):
+        x[c, :n] = oracle.fill_splitmix(n, dsp.SEED, c * n)
+    x[:, n:] = np.nan  # padding between channels must never be read into a result
+    y = np.full((nchan, stride), -7.0)
+    L = dsp.lib()
+    dsp._lib.check(L.dspx_fir_f64_batched(b.ctypes.data, b.size, x.ctypes.data, y.ctypes.data, nchan, n, stride, 1))
+    for c in range(nchan):
+        assert np.array_equal(bits(y[c, :n]), bits(oracle.lfilter(b, [1.0], x[c, :n])))
+    assert np.all(y[:, n:] == -7.0)  # and never written
+    # the same through device pointers, odd channel stride (scalar variant)
+    xd = torch.from_numpy(np.ascontiguousarray(x[:, :3003])).cuda()
+    yd = torch.full((nchan, 3003), -7.0, dtype=torch.float64, device="cuda")
+    dsp.fir_device(torch.from_numpy(b).cuda(), xd[:, :n], out=yd[:, :n], exact=True)
+    yh = yd.cpu().numpy()
+    for c in range(nchan):
+        assert np.array_equal(bits(yh[c, :n]), bits(oracle.lfilter(b, [1.0], x[c, :n])))
+    assert np.all(yh[:, n:] == -7.0)
+
+
+@pytest.mark.parametrize("ntaps", [2, 64, 255, 700])
+def test_history_makes_segments_seamless(dsp, oracle, torch, ntaps):
+    """Filtering a stream in segments, each given the previous ntaps-1 samples as history,
+    reproduces the one-shot result bit for bit (this is what segment sharding relies on)."""
+    n = 10000
+    b = oracle.firwin(ntaps, [0.2]) if ntaps > 2 else np.array([0.75, -0.25])
+    x = oracle.fill_splitmix(n, dsp.SEED, 31)
+    taps = torch.from_numpy(b).cuda()
+    xd = torch.from_numpy(x).cuda()
+    whole = dsp.fir_device(taps, xd).cpu().numpy()
+    assert scaled_err(whole, oracle.lfilter(b, [1.0], x)) <= TOL
+    cuts = [0, 1, ntaps // 2 + 1, 2048, 4097, 7777, n]
+    out = torch.empty_like(xd)
+    for a, e in zip(cuts[:-1], cuts[1:]):
+        hist = None
+        if a > 0:
+            h = np.zeros(ntaps - 1)
+            lead = min(ntaps - 1, a)
+            h[ntaps - 1 - lead:] = x[a - lead:a]
+            hist = torch.from_numpy(h).cuda()
+        dsp.fir_device(taps, xd[a:e], out=out[a:e], hist=hist)
+    assert np.array_equal(bits(out.cpu().numpy()), bits(whole))
+
+
+def test_host_path_piece_boundaries(dsp, oracle):
+    """One channel longer than a staging piece (2^24 samples): the pieces are stitched with history."""
+    n = (1 << 24) + 4321
+    b = oracle.firwin(31, [0.4])
+    x = oracle.fill_splitmix(n, dsp.SEED, 0)
+    ref = oracle.lfilter(b, [1.0], x)
+    y = dsp.lfilter(b, x, exact=True)
+    assert np.array_equal(bits(y), bits(ref))
+    y = dsp.lfilter_multi(b, x, ngpus=1)
+    assert scaled_err(y, ref) <= TOL
+
+
+def test_splitmix_fill_and_checksum_match_oracle(dsp, oracle, torch):
+    n = 100003
+    t = torch.empty(n, dtype=torch.float64, device="cuda")
+    dsp.fill_splitmix(t, dsp.SEED, 1 << 40)
+    host = oracle.fill_splitmix(n, dsp.SEED, 1 << 40)
+    assert np.array_equal(bits(t.cpu().numpy()), bits(host))
+    assert dsp.checksum(t, 77) == oracle.checksum(host, 77)
+    assert dsp.checksum(t[:0].contiguous(), 0) == 0
+
+
+def test_nan_inf_samples_stay_local(dsp, oracle):
+    """A non-finite sample poisons exactly the outputs the reference poisons."""
+    b = oracle.firwin(255, [0.25])
+    x = oracle.fill_splitmix(5000, 9, 0)
+    x[1234] = np.inf
+    x[4000] = np.nan
+    ref = oracle.lfilter(b, [1.0], x)
+    for exact in (True, False):
+        y = dsp.lfilter(b, x, exact=exact)
+        assert np.array_equal(np.isfinite(y), np.isfinite(ref))
