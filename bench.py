@@ -1,0 +1,220 @@
+#!/usr/bin/env python3
+"""Benchmark of the FIR hot path: dsp::firwin taps -> dsp::lfilter(b, 1.0, x) on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A step is one pass of the device-resident filter (dspx_fir_f64_dev) over one batch of
+synthetic input that already sits in HBM.  The default workload is the configuration the
+headline metric is quoted on: 4096 channels x 2^20 samples, 255-tap firwin(255, 0.25).
+With N > 1 (launched by torch.distributed.run, one rank per GPU) every rank filters its own
+batch of that size (weak scaling; channels are independent, so there is no data-path
+collective); `--scaling strong` shards the 4096 channels over the ranks instead.
+
+Rank 0 prints ONE JSON line with the metric, the roofline of the FIR kernel (per-launch HIP
+events on the launch stream) and, at N = 1, the CPU baseline (the oracle's single-threaded
+restatement of the reference loop, timed on a bounded sample of the same workload).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+WORKLOADS = {
+    # name: (nchan, n, numtaps, cutoff, description)
+    "batched255": (4096, 1 << 20, 255, 0.25,
+                   "batched multichannel 4096 x 2^20 samples, 255-tap firwin(255, 0.25) (BASELINE configs[2])"),
+    "long101": (1, 1 << 28, 101, 0.25, "single stream 2^28 samples, 101-tap firwin(101, 0.25) (BASELINE configs[1])"),
+    "long4095": (1, 1 << 26, 4095, 0.1, "single stream 2^26 samples, 4095-tap firwin(4095, 0.1) (BASELINE configs[3])"),
+    "small255": (64, 1 << 20, 255, 0.25, "reduced batch 64 x 2^20 samples, 255 taps (development only)"),
+}
+PEAK_FP64_TFLOPS = 78.6   # MI355X FP64: 256 CU x 64 FMA/clk x 2 x 2.4 GHz (vector; the FP64 MFMA peak is the same)
+PEAK_HBM_GBS = 8000.0     # MI355X HBM3E
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="batched255", choices=sorted(WORKLOADS))
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--exact", action="store_true", help="DSPX_FIR_EXACT arithmetic (separate mul/add)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-samples", type=int, default=1 << 26, help="samples of the workload the CPU baseline filters")
+    return ap.parse_args()
+
+
+def cpu_baseline(taps: np.ndarray, n: int, nsamples: int) -> dict:
+    """Times oracle/fir_oracle.c (single thread) on whole channels of the workload."""
+    from oracle.pyoracle import SEED, Oracle
+
+    orc = Oracle()
+    per = min(n, nsamples)
+    nchan = max(1, nsamples // per)
+    x = [orc.fill_splitmix(per, SEED, c * n) for c in range(nchan)]
+    t0 = time.perf_counter()
+    for c in range(nchan):
+        orc.lfilter(taps, [1.0], x[c])
+    dt = time.perf_counter() - t0
+    return {"value": nchan * per / dt / 1e9, "unit": "GS/s", "cores": 1, "kind": "port",
+            "sample": f"{nchan} channel(s) x {per} samples of the same workload, {taps.size} taps, {dt:.1f} s, "
+                      "oracle/fir_oracle.c gcc -O2 -ffp-contract=off (bit-identical to the reference loop)"}
+
+
+def sampled_parity(dsp, orc, taps, y, chan0, n, rows) -> float:
+    """max scaled error of a few output windows against the oracle (not timed)."""
+    from oracle.pyoracle import SEED
+
+    worst = 0.0
+    win = 4096
+    for r in rows:
+        for start in (0, n - win):
+            lead = min(start, taps.size - 1)
+            xs = orc.fill_splitmix(lead + win, SEED, (chan0 + r) * n + start - lead)
+            ref = orc.lfilter(taps, [1.0], xs)[lead:] if start == 0 else orc.fir_hist(taps, _hist(xs, lead, taps.size), xs[lead:])
+            got = y[r, start:start + win].cpu().numpy()
+            worst = max(worst, float(np.max(np.abs(got - ref)) / max(np.max(np.abs(ref)), 1e-300)))
+    return worst
+
+
+def _hist(xs, lead, ntaps):
+    h = np.zeros(ntaps - 1)
+    if lead:
+        h[ntaps - 1 - lead:] = xs[:lead]
+    return h
+
+
+def load_traffic(workload: str):
+    """HBM bytes per launch from the committed PMC summary, if one exists for this workload."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f).get(workload, {}).get("hbm_bytes_per_launch")
+    except (OSError, ValueError):
+        return None
+
+
+def main() -> None:
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with: python -m torch.distributed.run --nnodes=1 "
+                             "--nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+        raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
+
+    import torch
+    import torch.distributed as dist
+
+    import dsp_amd
+
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend=os.environ.get("DSPX_BENCH_BACKEND", "nccl"), device_id=dev)
+
+    nchan_total, n, numtaps, cutoff, desc = WORKLOADS[args.workload]
+    if args.scaling == "strong":
+        c_lo, c_hi = nchan_total * rank // world, nchan_total * (rank + 1) // world
+        nchan, chan0 = c_hi - c_lo, c_lo
+    else:
+        nchan, chan0 = nchan_total, rank * nchan_total
+    units_per_step_all = (nchan_total if args.scaling == "strong" else nchan_total * world) * n
+
+    taps_h = dsp_amd.firwin(numtaps, cutoff)
+    taps = torch.from_numpy(taps_h).to(dev)
+    x = torch.empty((nchan, n), dtype=torch.float64, device=dev)
+    y = torch.empty((nchan, n), dtype=torch.float64, device=dev)
+    dsp_amd.fill_splitmix(x, dsp_amd.SEED, chan0 * n)
+    torch.cuda.synchronize()
+
+    def step():
+        dsp_amd.fir_device(taps, x, out=y, exact=args.exact)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    fence()
+    t0 = time.perf_counter()
+    ev[0].record()
+    for i in range(args.steps):
+        step()
+        ev[i + 1].record()
+    fence()
+    dt = time.perf_counter() - t0
+    kern_ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps)]
+
+    t = torch.tensor([dt, float(np.mean(kern_ms))], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt_max, kern_ms_max = float(t[0]), float(t[1])
+
+    if rank == 0:
+        from oracle.pyoracle import Oracle
+
+        err = sampled_parity(dsp_amd, Oracle(), taps_h, y, chan0, n, sorted({0, nchan // 2, nchan - 1}))
+        outputs_per_launch = nchan * n
+        flops = 2.0 * numtaps * outputs_per_launch
+        bytes_alg = 16.0 * outputs_per_launch
+        sec = kern_ms_max / 1e3
+        fp64 = {"bound": "mfma", "achieved": flops / sec / 1e12, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
+                "frac": flops / sec / 1e12 / PEAK_FP64_TFLOPS, "traffic": load_traffic(args.workload),
+                "kernel": "fir_f64_kernel", "kernel_ms": kern_ms_max,
+                "note": "FP64 FMA on the vector ALU; on MI355X the FP64 MFMA peak equals the FP64 vector peak "
+                        "(78.6 TFLOP/s), so one number bounds both. algorithmic flops = 2*ntaps per output"}
+        hbm = {"bound": "hbm", "achieved": bytes_alg / sec / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+               "frac": bytes_alg / sec / 1e9 / PEAK_HBM_GBS, "traffic": load_traffic(args.workload),
+               "kernel": "fir_f64_kernel", "kernel_ms": kern_ms_max,
+               "note": "algorithmic bytes = 16 per output (8 read + 8 written)"}
+        # the binding roof is the one that allows fewer samples per second
+        fp64_roof_gs = PEAK_FP64_TFLOPS * 1e12 / (2.0 * numtaps) / 1e9
+        hbm_roof_gs = PEAK_HBM_GBS / 16.0
+        primary, secondary = (fp64, hbm) if fp64_roof_gs <= hbm_roof_gs else (hbm, fp64)
+        out = {
+            "metric": "FP64 FIR output GS/s (255 taps)" if numtaps == 255 else f"FP64 FIR output GS/s ({numtaps} taps)",
+            "value": units_per_step_all * args.steps / dt_max / 1e9,
+            "unit": "GS/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt_max / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": args.scaling,
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic (splitmix64 uniform [-1,1), generated on device, resident in HBM)",
+            "config": {"workload": desc, "nchan_per_gpu": nchan, "samples_per_channel": n, "ntaps": numtaps,
+                       "arithmetic": "exact (mul+add)" if args.exact else "fma",
+                       "sharding": "none" if world == 1 else ("channels" if args.scaling == "strong" else "independent batch per GPU")},
+            "roofline": primary,
+            "roofline_other": secondary,
+            "parity_max_scaled_err": err,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(taps_h, n, args.cpu_samples)
+        print(json.dumps(out), flush=True)
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,119 @@
+// Exercises include/dsp.hpp exactly as a user of the reference header would
+// (README.md:13-27 of the reference, and its test_firwin / test_lfilter, dsp.hpp:1476-1599):
+// same names, same template arguments, same call shapes.  Results are printed as
+// hex floats so that the Python side can compare bits.
+//
+//   dropin_check design <numtaps> <cutoff>            firwin only (no GPU needed)
+//   dropin_check readme                               firwin(100, 0.5) + lfilter over sin(n), n < 1024
+//   dropin_check filter <numtaps> <cutoff>  < samples lfilter(firwin(...), 1.0, x), x from stdin
+//   dropin_check api                                  overloads, ctx reuse, containers, error behaviour
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <iostream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "dsp.hpp"
+
+static void dump(const char* tag, const std::vector<double>& v) {
+    std::printf("%s %zu\n", tag, v.size());
+    for (double d : v) std::printf("%a\n", d);
+}
+
+template <typename E, typename F> static bool throws(F&& f) {
+    try {
+        f();
+    } catch (const E&) {
+        return true;
+    } catch (...) {
+        return false;
+    }
+    return false;
+}
+
+#define CHECK(cond)                                                      \
+    do {                                                                 \
+        if (!(cond)) {                                                   \
+            std::printf("FAIL %s:%d %s\n", __FILE__, __LINE__, #cond);   \
+            return 1;                                                    \
+        }                                                                \
+    } while (0)
+
+int main(int argc, char** argv) {
+    using namespace dsp;
+    const std::string mode = argc > 1 ? argv[1] : "";
+    if (mode == "design" && argc == 4) {
+        dump("taps", firwin<double>(std::strtoul(argv[2], nullptr, 10), std::strtod(argv[3], nullptr)));
+        return 0;
+    }
+    if (mode == "readme") {
+        std::vector<double> data(1024);
+        for (size_t n = 0; n < data.size(); ++n) data[n] = std::sin(static_cast<double>(n));
+        auto w = firwin(100, 0.5);
+        auto r = lfilter(w, 1.0, data);
+        dump("x", data);
+        dump("taps", w);
+        dump("y", r);
+        return 0;
+    }
+    if (mode == "filter" && argc == 4) {
+        std::vector<double> x;
+        std::string tok;
+        while (std::cin >> tok) x.push_back(std::strtod(tok.c_str(), nullptr));
+        auto w = firwin<double>(std::strtoul(argv[2], nullptr, 10), std::strtod(argv[3], nullptr));
+        auto r = lfilter<double>(w, 1.0, x);
+        dump("y", r);
+        return 0;
+    }
+    if (mode == "api") {
+        // argument errors of the design functions (reference dsp.hpp:76-78, 200-215)
+        CHECK(throws<std::invalid_argument>([] { firwin<double>(100, std::vector<double>{}); }));
+        CHECK(throws<std::invalid_argument>([] { firwin<double>(100, 0.5, false); }));
+        CHECK(throws<std::invalid_argument>([] { firwin<double>(1, 0.5); }));
+        CHECK(throws<std::invalid_argument>([] { hamming_window<double>(1); }));
+        CHECK(firwin<double>(101, 0.5, false).size() == 101);
+        CHECK(firwin<float>(33, 0.25f).size() == 33);
+        CHECK(std::abs(sinc<double>(0.0) - 1.0) < 1e-15);
+        if (argc > 2 && std::strcmp(argv[2], "nogpu") == 0) {
+            std::printf("OK (design only)\n");
+            return 0;
+        }
+        std::vector<double> x(5000);
+        for (size_t i = 0; i < x.size(); ++i) x[i] = std::cos(0.37 * static_cast<double>(i));
+        auto w = firwin<double>(64, 0.3);
+        // the three overloads agree
+        auto a = lfilter<double>(w, 1.0, x);
+        auto b = lfilter<double>(w, std::vector<double>{1.0}, x);
+        lfilter_ctx_t<double> ctx;
+        lfilter(ctx, w, std::vector<double>{1.0}, x);
+        CHECK(a == b && a == ctx.result && a.size() == x.size());
+        // the denominator value is never read (reference dsp.hpp:366)
+        CHECK(lfilter<double>(w, 2.0, x) == a);
+        // ctx.result is reused when the length matches, resized when it differs
+        const double* before = ctx.result.data();
+        lfilter(ctx, w, std::array<double, 1>{1.0}, x);
+        CHECK(ctx.result.data() == before);
+        std::vector<double> shorter(x.begin(), x.begin() + 100);
+        lfilter(ctx, w, std::array<double, 1>{1.0}, shorter);
+        CHECK(ctx.result.size() == 100);
+        for (size_t i = 0; i < 100; ++i) CHECK(ctx.result[i] == a[i]);
+        // non-contiguous container, std::array taps
+        std::deque<double> dq(x.begin(), x.end());
+        CHECK(lfilter<double>(w, 1.0, dq) == a);
+        // empty input -> empty output, empty numerators -> zeros
+        CHECK(lfilter<double>(w, 1.0, std::vector<double>{}).empty());
+        auto z = lfilter<double>(std::vector<double>{}, 1.0, x);
+        CHECK(z.size() == x.size());
+        for (double v : z) CHECK(v == 0.0);
+        // IIR denominators are outside the GPU path: loud error, no silent CPU fallback
+        CHECK(throws<std::invalid_argument>([&] { lfilter<double>(w, std::vector<double>{1.0, -0.5}, x); }));
+        std::printf("OK\n");
+        return 0;
+    }
+    std::fprintf(stderr, "usage: dropin_check design N C | readme | filter N C | api [nogpu]\n");
+    return 2;
+}
