@@ -65,9 +65,10 @@ int launch_dev(const double* d_taps, size_t ntaps, const double* d_x, size_t x_s
         s.hist_stride = hist_stride;
         s.y_stride = y_stride;
         s.n = (long long)n;
-        s.total_tiles = (unsigned long long)nc * tiles_per_chan;
+        s.total_tiles = (unsigned)(nc * tiles_per_chan);
         s.tiles_per_chan = (unsigned)tiles_per_chan;
         s.ntaps = (int)ntaps;
+        dspx::set_tile_divider(s);
         DSPX_HIP(dspx::launch_fir_f64(d_taps, d_x + c0 * x_stride, d_hist ? d_hist + c0 * hist_stride : nullptr,
                                       d_y + c0 * y_stride, s, (flags & DSPX_FIR_EXACT) != 0, vec2, stream));
     }

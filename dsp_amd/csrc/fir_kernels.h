@@ -9,10 +9,20 @@ struct FirShape {
     unsigned long long hist_stride;  // elements between channels of the history buffer
     unsigned long long y_stride;     // elements between channels of y
     long long n;                     // samples per channel
-    unsigned long long total_tiles;  // nchan * tiles_per_chan  (< 2^31)
+    unsigned long long div_magic;    // tile_id / tiles_per_chan == (tile_id * div_magic) >> div_shift
+    unsigned div_shift;
+    unsigned total_tiles;            // nchan * tiles_per_chan  (< 2^31)
     unsigned tiles_per_chan;         // ceil(n / fir_tile())
     int ntaps;
 };
+
+// Fills div_magic / div_shift for tiles_per_chan (exact for dividends below 2^31).
+inline void set_tile_divider(FirShape& s) {
+    unsigned l = 0;
+    while ((1ull << l) < s.tiles_per_chan) ++l;
+    s.div_shift = 31 + l;
+    s.div_magic = ((1ull << s.div_shift) + s.tiles_per_chan - 1) / s.tiles_per_chan;
+}
 
 int fir_tile();  // outputs per workgroup
 

@@ -37,13 +37,16 @@ constexpr int kTile = kBlock * kR;        // outputs per workgroup
 constexpr int kStageTaps = 256;           // taps per LDS stage
 constexpr int kHalo = kStageTaps;         // window slots in front of the tile
 constexpr int kSlots = kHalo + kTile;     // window slots per stage
-constexpr int kLdsDoubles = kSlots + kSlots / 4;
+constexpr int kLdsPairs = (kSlots + kSlots / 4) / 2;             // 16-byte pairs in the padded image
 constexpr int kStageIters = (kSlots / 2 + kBlock - 1) / kBlock;  // 16-byte loads per thread per stage
 
 static_assert(kR == 8 && kGroup == 16, "the window indexing below assumes 8 outputs per thread, 16-tap groups");
-static_assert(kHalo % 8 == 0 && kTile % 8 == 0 && kStageTaps % kGroup == 0, "padding groups must align");
+static_assert(kHalo % 16 == 0 && kTile % 8 == 0 && kStageTaps % kGroup == 0, "padding groups must align");
+static_assert(kStageIters == 5 && (kStageIters - 1) * 2 * kBlock <= kTile, "only the last staging pass is partial");
 
-__device__ __forceinline__ int padded(int q) { return q + 2 * (q >> 3); }
+// The image stores slot q at double index q + 2*(q/8); an even slot q and its neighbour
+// q+1 form the 16-byte pair with this index.
+__host__ __device__ constexpr int pair_of(int q) { return (q >> 1) + (q >> 3); }
 
 template <bool EXACT> __device__ __forceinline__ double mac(double b, double w, double acc) {
     if constexpr (EXACT) {
@@ -66,20 +69,22 @@ __device__ __forceinline__ double sample_at(const double* __restrict__ xc, const
 
 // Loads the 24 samples that taps [16g, 16g+16) of a stage touch for one thread.
 // W[i] is the sample that tap 16g + t multiplies into output r when i = t - r + 7, i.e.
-// image slot kHalo - 16g + 8*tid + 7 - i.  `top` points at the slot of i = 0 for g = 0;
-// the slots of i = 8m .. 8m+7 are the 8 consecutive doubles that END at top - 10*(2g+m),
-// read here as four aligned 16-byte pairs.
-__device__ __forceinline__ void load_window(const double* top, int g, double (&W)[kWin]) {
-    const double* p = top - 20 * g;
+// image slot kHalo - 16g + 8*tid + 7 - i.  Slots (i+1, i) for even i form the aligned pair
+// pair_of(kHalo + 8*tid + 6) - 10g - 5*(i/8) - (i%8)/2; `top` points at the pair of i = 0, g = 0.
+__device__ __forceinline__ void load_window(const double2* top, int g, double (&W)[kWin]) {
+    const double2* p = top - 10 * g;
 #pragma unroll
     for (int m = 0; m < 3; ++m) {
 #pragma unroll
         for (int h = 0; h < 4; ++h) {
-            const double2 v = *reinterpret_cast<const double2*>(p - 10 * m - 2 * h - 1);
+            const double2 v = p[-5 * m - h];
             W[8 * m + 2 * h] = v.y;
             W[8 * m + 2 * h + 1] = v.x;
         }
     }
+    // W[23] is never multiplied; keeping it "used" stops the compiler from splitting the
+    // bottom row of 16-byte reads into 8-byte ones (ds_read2_b64 is slower and conflicts).
+    asm volatile("" ::"v"(W[kWin - 1]));
 }
 
 template <bool EXACT, bool VEC2>
@@ -87,22 +92,23 @@ __global__ __launch_bounds__(kBlock) void fir_f64_kernel(const double* __restric
                                                           const double* __restrict__ x,
                                                           const double* __restrict__ hist, double* __restrict__ y,
                                                           FirShape s) {
-    __shared__ __attribute__((aligned(16))) double lds[kLdsDoubles];
+    __shared__ double2 lds[kLdsPairs];
     const int tid = threadIdx.x;
 
     // Blocks b and b+8 share an XCD (and its L2): give every XCD a contiguous range
     // of tiles so that neighbouring tiles find their shared halo in the same L2.
-    const unsigned long long b = blockIdx.x;
-    const unsigned long long q8 = s.total_tiles / 8, r8 = s.total_tiles % 8;
-    const unsigned long long grp = b % 8, k = b / 8;
-    const unsigned long long tile_id = (grp < r8 ? grp * (q8 + 1) : r8 * (q8 + 1) + (grp - r8) * q8) + k;
-
-    const unsigned long long chan = tile_id / s.tiles_per_chan;
-    const long long tile_start = (long long)(tile_id % s.tiles_per_chan) * kTile;
-    const double* __restrict__ xc = x + chan * s.x_stride;
-    const double* __restrict__ hc = hist ? hist + chan * s.hist_stride : nullptr;
+    const unsigned b = blockIdx.x;
+    const unsigned q8 = s.total_tiles / 8, r8 = s.total_tiles % 8;
+    const unsigned grp = b % 8, k = b / 8;
+    const unsigned tile_id = (grp < r8 ? grp * (q8 + 1) : r8 * (q8 + 1) + (grp - r8) * q8) + k;
+    // tile_id / tiles_per_chan by multiplication (exact for tile_id < 2^31)
+    const unsigned chan = (unsigned)(((unsigned long long)tile_id * s.div_magic) >> s.div_shift);
+    const long long tile_start = (long long)(tile_id - chan * s.tiles_per_chan) * kTile;
+    const double* __restrict__ xc = x + (unsigned long long)chan * s.x_stride;
+    const double* __restrict__ hc = hist ? hist + (unsigned long long)chan * s.hist_stride : nullptr;
     const long long n = s.n;
     const int ntaps = s.ntaps;
+    const int stage_pair = tid + (tid >> 2);  // pair_of(2*tid): where this thread's staged pairs go
 
     double acc[kR];
 #pragma unroll
@@ -113,48 +119,43 @@ __global__ __launch_bounds__(kBlock) void fir_f64_kernel(const double* __restric
         const int ngroups = S / kGroup;
         const int rem = S % kGroup;
 
-        // ---- stage the window: slot q <- sample tile_start - j0 - kHalo + q ----
-        const long long g0 = tile_start - j0 - kHalo;
-        // lowest slot the window loads of this stage touch (whole 16-tap groups, a multiple of 8)
-        const int qlo = kHalo - kGroup * (ngroups + (rem ? 1 : 0));
-        if (j0 > 0) __syncthreads();  // readers of the previous stage are done
-        double v0[kStageIters], v1[kStageIters];
-        if (g0 + qlo >= 0 && g0 + kSlots <= n) {  // interior tile (workgroup-uniform): no edge tests
+        // ---- stage the window: slot q <- sample tile_start - j0 - kHalo + q, for q >= qlo ----
+        const int qlo = kHalo - kGroup * (ngroups + (rem ? 1 : 0));  // lowest slot the window loads touch
+        const int npairs = (kSlots - qlo) / 2;
+        const long long g_lo = tile_start - j0 - kHalo + qlo;        // sample held by slot qlo
+        if (j0 > 0) __syncthreads();                                  // readers of the previous stage are done
+        double2 v[kStageIters];
+        if (g_lo >= 0 && g_lo + (kSlots - qlo) <= n) {  // interior tile (workgroup-uniform): no edge tests
+            const double* __restrict__ src = xc + g_lo;
 #pragma unroll
             for (int i = 0; i < kStageIters; ++i) {
-                const int q = qlo + 2 * (tid + i * kBlock);
-                v0[i] = 0.0, v1[i] = 0.0;
-                if (q < kSlots) {
-                    if constexpr (VEC2) {
-                        const double2 v = *reinterpret_cast<const double2*>(xc + (g0 + q));
-                        v0[i] = v.x, v1[i] = v.y;
-                    } else {
-                        v0[i] = xc[g0 + q], v1[i] = xc[g0 + q + 1];
-                    }
+                const int pi = tid + i * kBlock;
+                if (i < kStageIters - 1 || pi < npairs) {
+                    if constexpr (VEC2)
+                        v[i] = reinterpret_cast<const double2*>(src)[pi];
+                    else
+                        v[i] = make_double2(src[2 * pi], src[2 * pi + 1]);
                 }
             }
         } else {
 #pragma unroll
             for (int i = 0; i < kStageIters; ++i) {
-                const int q = qlo + 2 * (tid + i * kBlock);
-                v0[i] = 0.0, v1[i] = 0.0;
-                if (q < kSlots) {
-                    v0[i] = sample_at(xc, hc, g0 + q, n, ntaps);
-                    v1[i] = sample_at(xc, hc, g0 + q + 1, n, ntaps);
-                }
+                const int pi = tid + i * kBlock;
+                if (i < kStageIters - 1 || pi < npairs)
+                    v[i] = make_double2(sample_at(xc, hc, g_lo + 2 * pi, n, ntaps),
+                                        sample_at(xc, hc, g_lo + 2 * pi + 1, n, ntaps));
             }
         }
+        double2* stage = lds + pair_of(qlo) + stage_pair;
 #pragma unroll
         for (int i = 0; i < kStageIters; ++i) {
-            const int q = qlo + 2 * (tid + i * kBlock);
-            if (q < kSlots)  // q is even: q and q+1 share a padding group and a 16-byte slot
-                *reinterpret_cast<double2*>(lds + padded(q)) = make_double2(v0[i], v1[i]);
+            if (i < kStageIters - 1 || tid + i * kBlock < npairs) stage[i * pair_of(2 * kBlock)] = v[i];
         }
         __syncthreads();
 
         // ---- accumulate the stage's taps, 16 per group ----
         const double* __restrict__ tp = taps + j0;
-        const double* top = lds + padded(kHalo + 8 * tid + 7);
+        const double2* top = lds + pair_of(kHalo + 6) + 5 * tid;
         for (int g = 0; g < ngroups; ++g) {
             double W[kWin], bt[kGroup];
             load_window(top, g, W);
@@ -184,26 +185,30 @@ __global__ __launch_bounds__(kBlock) void fir_f64_kernel(const double* __restric
         }
     }
 
-    // ---- store the tile: accumulators -> LDS (stride 10) -> coalesced 16-byte stores ----
+    // ---- store the tile: accumulators -> LDS (stride 5 pairs) -> coalesced 16-byte stores ----
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < kR; r += 2)
-        *reinterpret_cast<double2*>(lds + padded(8 * tid + r)) = make_double2(acc[r], acc[r + 1]);
+    for (int r = 0; r < kR; r += 2) lds[5 * tid + r / 2] = make_double2(acc[r], acc[r + 1]);
     __syncthreads();
-    double* __restrict__ yc = y + chan * s.y_stride;
+    double* __restrict__ yt = y + (unsigned long long)chan * s.y_stride + tile_start;
+    const double2* back = lds + stage_pair;
+    const long long left = n - tile_start;  // outputs of this channel from tile_start on
 #pragma unroll
     for (int i = 0; i < kTile / 2 / kBlock; ++i) {
-        const int q = 2 * (tid + i * kBlock);
-        const long long g = tile_start + q;
-        const double2 o = *reinterpret_cast<const double2*>(lds + padded(q));
-        if (g + 1 < n) {
-            if constexpr (VEC2) {
-                *reinterpret_cast<double2*>(yc + g) = o;
-            } else {
-                yc[g] = o.x, yc[g + 1] = o.y;
-            }
-        } else if (g < n) {
-            yc[g] = o.x;
+        const int pi = tid + i * kBlock;
+        const double2 o = back[i * pair_of(2 * kBlock)];
+        if (left >= kTile) {  // full tile (workgroup-uniform)
+            if constexpr (VEC2)
+                reinterpret_cast<double2*>(yt)[pi] = o;
+            else
+                yt[2 * pi] = o.x, yt[2 * pi + 1] = o.y;
+        } else if (2 * pi + 1 < left) {
+            if constexpr (VEC2)
+                reinterpret_cast<double2*>(yt)[pi] = o;
+            else
+                yt[2 * pi] = o.x, yt[2 * pi + 1] = o.y;
+        } else if (2 * pi < left) {
+            yt[2 * pi] = o.x;
         }
     }
 }
@@ -247,7 +252,7 @@ int fir_tile() { return kTile; }
 hipError_t launch_fir_f64(const double* taps, const double* x, const double* hist, double* y, const FirShape& shape,
                           bool exact, bool vec2, hipStream_t stream) {
     if (shape.total_tiles == 0) return hipSuccess;
-    const dim3 grid((unsigned)shape.total_tiles), block(kBlock);
+    const dim3 grid(shape.total_tiles), block(kBlock);
     if (exact) {
         if (vec2)
             hipLaunchKernelGGL((fir_f64_kernel<true, true>), grid, block, 0, stream, taps, x, hist, y, shape);

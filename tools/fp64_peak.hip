@@ -1,0 +1,109 @@
+// Calibration microbenchmark (not part of the library): sustained FP64 rate of the chip with
+// operands in registers -- v_fma_f64 (vector) and v_mfma_f64_16x16x4_f64 (matrix) -- and the
+// clock the chip holds while doing it, over runs long enough for DVFS to settle.
+//   hipcc --offload-arch=gfx950 -O3 -o tools/fp64_peak tools/fp64_peak.hip
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <vector>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return; } } while (0)
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+template <int ACC>
+__global__ __launch_bounds__(256) void fma_loop(double* out, int iters, double a, double b, unsigned long long* clk) {
+    double acc[ACC];
+#pragma unroll
+    for (int i = 0; i < ACC; ++i) acc[i] = threadIdx.x * 1e-9 + i;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int i = 0; i < ACC; ++i) acc[i] = __builtin_fma(acc[i], a, b);
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+    double s = 0;
+#pragma unroll
+    for (int i = 0; i < ACC; ++i) s += acc[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    if (threadIdx.x == 0) {
+        clk[2 * blockIdx.x] = t1 - t0;
+        clk[2 * blockIdx.x + 1] = r1 - r0;
+    }
+}
+
+template <int ACC>
+__global__ __launch_bounds__(256) void mfma_loop(double* out, int iters, double a, double b, unsigned long long* clk) {
+    d4 acc[ACC];
+#pragma unroll
+    for (int i = 0; i < ACC; ++i) acc[i] = d4{0.0, 0.0, 0.0, 0.0};
+    double av = a + threadIdx.x * 1e-9, bv = b;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int i = 0; i < ACC; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[i], 0, 0, 0);
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+    double s = 0;
+#pragma unroll
+    for (int i = 0; i < ACC; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    if (threadIdx.x == 0) {
+        clk[2 * blockIdx.x] = t1 - t0;
+        clk[2 * blockIdx.x + 1] = r1 - r0;
+    }
+}
+
+template <typename K> void run(const char* name, K kernel, double flops_per_thread_iter, int blocks_per_cu, int iters, double seconds) {
+    const int blocks = 256 * blocks_per_cu;
+    double* out;
+    unsigned long long* clk;
+    CK(hipMalloc(&out, sizeof(double) * blocks * 256));
+    CK(hipMalloc(&clk, sizeof(unsigned long long) * 2 * blocks));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), 0, 0, out, iters, 0.999999, 1e-7, clk);
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), 0, 0, out, iters, 0.999999, 1e-7, clk);
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms1;
+    CK(hipEventElapsedTime(&ms1, e0, e1));
+    const int reps = (int)(seconds * 1e3 / ms1) + 1;
+    CK(hipEventRecord(e0));
+    for (int w = 0; w < reps; ++w) hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), 0, 0, out, iters, 0.999999, 1e-7, clk);
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    const double flops = flops_per_thread_iter * iters * 256.0 * blocks * reps;
+    std::vector<unsigned long long> h(2 * blocks);
+    CK(hipMemcpy(h.data(), clk, sizeof(unsigned long long) * 2 * blocks, hipMemcpyDeviceToHost));
+    double ghz = 0;
+    for (int i = 0; i < blocks; ++i) ghz += (double)h[2 * i] / (double)h[2 * i + 1] * 0.1;
+    printf("%-10s waves/SIMD=%d  first launch %.2f TFLOP/s, sustained %.2f TFLOP/s over %.2f s, clock at end %.3f GHz\n", name,
+           blocks_per_cu, flops / reps / (ms1 * 1e-3) / 1e12, flops / (ms * 1e-3) / 1e12, ms * 1e-3, ghz / blocks);
+    CK(hipFree(out));
+    CK(hipFree(clk));
+}
+
+int main() {
+    run("fma acc8", fma_loop<8>, 2.0 * 8 * 8, 4, 10000, 0.05);
+    run("fma acc8", fma_loop<8>, 2.0 * 8 * 8, 4, 10000, 2.0);
+    run("fma acc8", fma_loop<8>, 2.0 * 8 * 8, 2, 10000, 2.0);
+    // one MFMA = 16*16*4*2 flops per wave = 32 flops per lane
+    run("mfma acc4", mfma_loop<4>, 32.0 * 4 * 4, 1, 10000, 2.0);
+    run("mfma acc4", mfma_loop<4>, 32.0 * 4 * 4, 2, 10000, 2.0);
+    run("mfma acc8", mfma_loop<8>, 32.0 * 8 * 4, 1, 5000, 2.0);
+    run("mfma acc2", mfma_loop<2>, 32.0 * 2 * 4, 4, 10000, 2.0);
+    return 0;
+}

@@ -1,0 +1,22 @@
+#!/bin/bash
+# Profiles the headline benchmark on the GPU box: kernel-trace statistics, then PMC
+# counter passes (each in a run of its own).  Outputs under gpurun_out/prof_<tag>/.
+#   tools/profile.sh <tag> [bench args...]
+set -u
+TAG=${1:-run}; shift || true
+ARGS="--steps 5 --warmup 1 --no-cpu-baseline $*"
+OUT=gpurun_out/prof_$TAG
+mkdir -p $OUT
+cd /tmp 2>/dev/null && export TMPDIR=/tmp && cd - >/dev/null
+timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py $ARGS > $OUT/stats.log 2>&1 || { echo "stats pass failed"; tail -5 $OUT/stats.log; exit 1; }
+pass() {  # name counters...
+  local name=$1; shift
+  timeout -s KILL 300 rocprofv3 --pmc "$@" --output-format csv -d $OUT/$name -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline ${EXTRA:-} > $OUT/$name.log 2>&1 || { echo "pmc pass $name failed"; tail -5 $OUT/$name.log; exit 1; }
+}
+EXTRA="$*"
+pass sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY &&
+pass sq2 SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS &&
+pass fetch FETCH_SIZE &&
+pass write WRITE_SIZE &&
+pass grbm GRBM_GUI_ACTIVE &&
+echo "profile ok: $OUT"
