@@ -14,6 +14,11 @@ DSPX_OK = 0
 DSPX_FIR_FMA = 0
 DSPX_FIR_EXACT = 1
 
+class Piece(C.Structure):
+    _fields_ = [("device", C.c_int), ("chan", C.c_size_t), ("nchan", C.c_size_t), ("start", C.c_size_t),
+                ("len", C.c_size_t)]
+
+
 # name -> (restype, argtypes); one entry per declaration in include/dspx.h
 SIGNATURES = {
     "dspx_version": (C.c_int, []),
@@ -28,6 +33,7 @@ SIGNATURES = {
                                        C.c_size_t, C.c_uint]),
     "dspx_fir_f64_multi": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t,
                                      C.c_size_t, C.c_int, C.c_uint]),
+    "dspx_fir_plan": (C.c_long, [C.c_size_t, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t]),
     "dspx_fir_f64_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
                                    C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_uint, C.c_void_p]),
     "dspx_fill_splitmix_f64_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_uint64, C.c_uint64, C.c_void_p]),

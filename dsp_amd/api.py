@@ -59,6 +59,16 @@ def lfilter_multi(b, x, ngpus: int = 0, exact: bool = False) -> np.ndarray:
     return y.reshape(x.shape)
 
 
+def fir_plan(nchan: int, n: int, ngpus: int):
+    """The multi-GPU sharding plan as a list of (device, chan, nchan, start, len) tuples."""
+    total = lib().dspx_fir_plan(nchan, n, ngpus, None, 0)
+    if total < 0:
+        check(int(total))
+    arr = (_lib.Piece * max(int(total), 1))()
+    lib().dspx_fir_plan(nchan, n, ngpus, C.cast(arr, C.c_void_p), total)
+    return [(p.device, p.chan, p.nchan, p.start, p.len) for p in arr[:total]]
+
+
 # ---- torch device tensors ----------------------------------------------------------
 
 def _stream_ptr():

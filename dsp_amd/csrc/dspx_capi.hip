@@ -107,6 +107,18 @@ void cut_pieces(size_t c0, size_t c1, size_t s0, size_t s1, std::vector<Piece>& 
     }
 }
 
+// Work of each of G devices: contiguous channel ranges when there are at least G channels,
+// otherwise contiguous segments of every channel.
+std::vector<std::vector<Piece>> make_plan(size_t nchan, size_t n, int G) {
+    std::vector<std::vector<Piece>> plan(G);
+    if (nchan >= (size_t)G) {
+        for (int g = 0; g < G; ++g) cut_pieces(nchan * g / G, nchan * (g + 1) / G, 0, n, plan[g]);
+    } else {
+        for (int g = 0; g < G; ++g) cut_pieces(0, nchan, n * g / G, n * (g + 1) / G, plan[g]);
+    }
+    return plan;
+}
+
 struct Slot {
     double *d_in = nullptr, *d_out = nullptr;
     size_t in_cap = 0, out_cap = 0;
@@ -202,12 +214,7 @@ int host_path(const double* taps, size_t ntaps, const double* x, double* y, size
     }
     const int G = ngpus == 0 ? ndev : ngpus;
     if (G > ndev) return fail(DSPX_ERR_INVALID, "ngpus (%d) exceeds visible devices (%d)", G, ndev);
-    std::vector<std::vector<Piece>> plan(G);
-    if (nchan >= (size_t)G) {  // contiguous channel ranges
-        for (int g = 0; g < G; ++g) cut_pieces(nchan * g / G, nchan * (g + 1) / G, 0, n, plan[g]);
-    } else {  // contiguous segments of every channel
-        for (int g = 0; g < G; ++g) cut_pieces(0, nchan, n * g / G, n * (g + 1) / G, plan[g]);
-    }
+    const std::vector<std::vector<Piece>> plan = make_plan(nchan, n, G);
     std::vector<int> rcs(G, DSPX_OK);
     std::vector<std::string> msgs(G);
     std::vector<std::thread> workers;
@@ -289,6 +296,19 @@ int dspx_fir_f64_multi(const double* taps, size_t ntaps, const double* x, double
                        size_t stride, int ngpus, unsigned flags) {
     if (ngpus < 0) return fail(DSPX_ERR_INVALID, "ngpus must be >= 0");
     return host_path(taps, ntaps, x, y, nchan, n, stride, ngpus, flags);
+}
+
+long dspx_fir_plan(size_t nchan, size_t n, int ngpus, dspx_piece* out, size_t cap) {
+    if (ngpus < 1) return fail(DSPX_ERR_INVALID, "ngpus must be >= 1");
+    if (cap && !out) return fail(DSPX_ERR_INVALID, "out is NULL");
+    const auto plan = make_plan(nchan, n, ngpus);
+    size_t k = 0;
+    for (int g = 0; g < ngpus; ++g)
+        for (const Piece& p : plan[g]) {
+            if (k < cap) out[k] = dspx_piece{g, p.c, p.cnt, p.s0, p.len};
+            ++k;
+        }
+    return (long)k;
 }
 
 int dspx_fir_f64_dev(const double* d_taps, size_t ntaps, const double* d_x, size_t x_stride, const double* d_hist,

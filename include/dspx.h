@@ -82,6 +82,18 @@ DSPX_API int dspx_fir_f64_batched(const double* taps, size_t ntaps, const double
 DSPX_API int dspx_fir_f64_multi(const double* taps, size_t ntaps, const double* x, double* y, size_t nchan, size_t n,
                        size_t stride, int ngpus, unsigned flags);
 
+/* The sharding plan dspx_fir_f64_multi executes, exposed so that it can be inspected and
+ * tested without GPUs: piece i covers channels [chan, chan + nchan) x samples
+ * [start, start + len) and is assigned to `device`; the pieces of one device are staged
+ * through HBM in order.  A piece with start > 0 is filtered with the min(start, ntaps-1)
+ * samples before it as history (zeros before the channel start).  Writes at most `cap`
+ * pieces to `out` and returns the total number of pieces (or a negative dspx_status). */
+typedef struct dspx_piece {
+    int device;
+    size_t chan, nchan, start, len;
+} dspx_piece;
+DSPX_API long dspx_fir_plan(size_t nchan, size_t n, int ngpus, dspx_piece* out, size_t cap);
+
 /* ---- device-resident entry point ------------------------------------------------
  * All pointers are device pointers on the current device; the launch is asynchronous
  * on `stream`.  d_hist, when non-NULL, holds for every channel c the ntaps-1 samples

@@ -1,0 +1,143 @@
+"""Parity at the benchmark's full sizes (BASELINE.json configs 2-4), where the CPU oracle
+cannot filter everything: sampled windows against the oracle, plus size-independent
+properties that must hold bit for bit -- sharding invariance (a checksum of the whole output
+is the same however the work is cut into channel ranges or history-carrying segments, which
+is what 1/2/4/8-GPU runs rely on), shift invariance across tile boundaries, and the unit DC
+gain of a scaled low-pass design."""
+import numpy as np
+import pytest
+
+from conftest import scaled_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-12
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+
+    import dsp_amd
+
+    assert torch.cuda.is_available() and dsp_amd.device_count() >= 1
+    return torch, dsp_amd
+
+
+def check_window(dsp, oracle, taps_h, y_row, chan_offset, start, win=4096):
+    """Compares y_row[start:start+win] with the oracle run on regenerated input."""
+    ntaps = taps_h.size
+    lead = min(start, ntaps - 1)
+    xs = oracle.fill_splitmix(lead + win, dsp.SEED, chan_offset + start - lead)
+    hist = None
+    if start > 0:
+        hist = np.zeros(ntaps - 1)
+        hist[ntaps - 1 - lead:] = xs[:lead]
+    ref = oracle.fir_hist(taps_h, hist, xs[lead:])
+    got = y_row[start:start + win].cpu().numpy()
+    assert scaled_err(got, ref) <= TOL, (chan_offset, start, scaled_err(got, ref))
+
+
+def test_batched_255_taps_4096x2e20(env, oracle, golden):
+    torch, dsp = env
+    nchan, n = 4096, 1 << 20
+    taps_h = dsp.firwin(255, 0.25)
+    assert np.array_equal(bits(taps_h), bits(golden["taps_255_0p25"]))
+    taps = torch.from_numpy(taps_h).cuda()
+    x = torch.empty((nchan, n), dtype=torch.float64, device="cuda")
+    y = torch.empty_like(x)
+    dsp.fill_splitmix(x, dsp.SEED, 0)
+    dsp.fir_device(taps, x, out=y)
+    # sampled windows: start / interior tile boundary / end of first, middle and last channels;
+    # channel c+1 must start from zero state, not from channel c's tail
+    for c in (0, 1, 2047, 4095):
+        for start in (0, 2048 - 100, (1 << 19) + 5, n - 4096):
+            check_window(dsp, oracle, taps_h, y[c], c * n, start)
+    # the first 2^14 outputs of channel 0 are the committed reference output itself
+    assert scaled_err(y[0, :1 << 14].cpu().numpy(), golden["seeded_y_taps_255_0p25"]) <= TOL
+    whole = dsp.checksum(y, 0)
+    # channel sharding as 8 GPUs would do it: 8 separate launches over contiguous channel ranges
+    y.zero_()
+    for g in range(8):
+        lo, hi = nchan * g // 8, nchan * (g + 1) // 8
+        dsp.fir_device(taps, x[lo:hi], out=y[lo:hi])
+    assert dsp.checksum(y, 0) == whole
+    # checksum of checksums: per-range sums add up to the whole
+    parts = sum(dsp.checksum(y[nchan * g // 8: nchan * (g + 1) // 8], (nchan * g // 8) * n) for g in range(8))
+    assert parts & (2**64 - 1) == whole
+    # exact mode agrees with FMA mode to rounding on a few channels, and is itself bit-exact vs the oracle
+    ye = dsp.fir_device(taps, x[:2], exact=True)
+    assert scaled_err(y[:2].cpu().numpy(), ye.cpu().numpy()) <= TOL
+    xs = oracle.fill_splitmix(1 << 16, dsp.SEED, 0)
+    assert np.array_equal(bits(ye[0, :1 << 16].cpu().numpy()), bits(oracle.lfilter(taps_h, [1.0], xs)))
+
+
+@pytest.mark.parametrize("numtaps,cutoff,log2n,key", [(101, 0.25, 28, "taps_101_0p25"), (4095, 0.1, 26, "taps_4095_0p1")])
+def test_long_stream_segment_sharding(env, oracle, golden, numtaps, cutoff, log2n, key):
+    torch, dsp = env
+    n = 1 << log2n
+    taps_h = dsp.firwin(numtaps, cutoff)
+    assert np.array_equal(bits(taps_h), bits(golden[key]))
+    taps = torch.from_numpy(taps_h).cuda()
+    x = torch.empty(n, dtype=torch.float64, device="cuda")
+    y = torch.empty_like(x)
+    dsp.fill_splitmix(x, dsp.SEED, 0)
+    dsp.fir_device(taps, x, out=y)
+    assert scaled_err(y[:1 << 14].cpu().numpy(), golden["seeded_y_" + key]) <= TOL
+    for start in (0, 2048 - 7, n // 8 - 2000, n // 2 + 12345, n - 4096):
+        check_window(dsp, oracle, taps_h, y, 0, start)
+    whole = dsp.checksum(y, 0)
+    # segment sharding as 8 GPUs would do it: each segment sees the ntaps-1 samples before it
+    y2 = torch.zeros_like(x)
+    for g in range(8):
+        lo, hi = n * g // 8, n * (g + 1) // 8
+        hist = x[lo - (numtaps - 1): lo] if g else None
+        dsp.fir_device(taps, x[lo:hi], out=y2[lo:hi], hist=hist)
+    assert dsp.checksum(y2, 0) == whole
+    # uneven cuts that do not fall on tile boundaries
+    cuts = [0, 1, numtaps // 2, 5000, n // 3 + 1, n - 3, n]
+    y2.zero_()
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        if lo == 0:
+            hist = None
+        else:
+            lead = min(lo, numtaps - 1)
+            hist = torch.zeros(numtaps - 1, dtype=torch.float64, device="cuda")
+            hist[numtaps - 1 - lead:] = x[lo - lead: lo]
+        dsp.fir_device(taps, x[lo:hi], out=y2[lo:hi], hist=hist)
+    assert dsp.checksum(y2, 0) == whole
+
+
+def test_shift_invariance_across_tiles(env):
+    """Delaying the input by k samples delays the output by k samples, bit for bit, for delays
+    that move every sample to a different place in its tile."""
+    torch, dsp = env
+    n = 1 << 22
+    taps = torch.from_numpy(dsp.firwin(255, 0.25)).cuda()
+    x = torch.empty(n, dtype=torch.float64, device="cuda")
+    dsp.fill_splitmix(x, dsp.SEED, 42)
+    y = dsp.fir_device(taps, x)
+    for k in (1, 7, 1000, 2047, 2049):
+        xs = torch.zeros(n + k, dtype=torch.float64, device="cuda")
+        xs[k:] = x
+        ys = dsp.fir_device(taps, xs)
+        assert torch.equal(ys[k:], y) and bool((ys[:k] == 0).all())
+
+
+def test_unit_dc_gain_everywhere(env):
+    """firwin(..., scale=True) low-pass taps sum to one: a constant input settles to the same
+    constant, identically (same bits) at every steady-state sample of every channel."""
+    torch, dsp = env
+    taps_h = dsp.firwin(255, 0.25)
+    taps = torch.from_numpy(taps_h).cuda()
+    x = torch.ones((64, 1 << 20), dtype=torch.float64, device="cuda")
+    y = dsp.fir_device(taps, x)
+    steady = y[:, 254:]
+    v = float(steady[0, 0])
+    assert abs(v - 1.0) < 1e-14
+    assert bool((steady == v).all())
+    # warm-up samples are the running sums of the taps in ascending order (FMA with 1.0 is exact)
+    assert np.array_equal(bits(y[3, :254].cpu().numpy()), bits(np.cumsum(taps_h)[:254]))

@@ -36,19 +36,66 @@ __global__ __launch_bounds__(256) void fma_loop(double* out, int iters, double a
     }
 }
 
+// Same loop with per-lane pseudo-random multiplicands and addends (random mantissa bits
+// toggle far more logic than loop-invariant operands do, which lowers the clock the
+// chip can hold).
+template <int ACC>
+__global__ __launch_bounds__(256) void fma_loop_random(double* out, int iters, double a, double b, unsigned long long* clk) {
+    double acc[ACC], xm[ACC], ya[ACC];
+    unsigned long long z = 0x9E3779B97F4A7C15ull * (blockIdx.x * 256 + threadIdx.x + 1);
+#pragma unroll
+    for (int i = 0; i < ACC; ++i) {
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;
+        xm[i] = (double)(z >> 11) * 0x1.0p-53 * a;
+        z += 0x9E3779B97F4A7C15ull;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;
+        ya[i] = (double)(z >> 11) * 0x1.0p-53 - 0.5 + b;
+        acc[i] = ya[i];
+    }
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int i = 0; i < ACC; ++i) acc[i] = __builtin_fma(acc[i], xm[(i + u) % ACC], ya[(i + 3 * u) % ACC]);
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+    double s = 0;
+#pragma unroll
+    for (int i = 0; i < ACC; ++i) s += acc[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    if (threadIdx.x == 0) {
+        clk[2 * blockIdx.x] = t1 - t0;
+        clk[2 * blockIdx.x + 1] = r1 - r0;
+    }
+}
+
 template <int ACC>
 __global__ __launch_bounds__(256) void mfma_loop(double* out, int iters, double a, double b, unsigned long long* clk) {
     d4 acc[ACC];
 #pragma unroll
     for (int i = 0; i < ACC; ++i) acc[i] = d4{0.0, 0.0, 0.0, 0.0};
-    double av = a + threadIdx.x * 1e-9, bv = b;
+    // per-lane pseudo-random A and B operands, four of each, cycled through the unrolled body
+    double av4[4], bv4[4];
+    unsigned long long z = 0x9E3779B97F4A7C15ull * (blockIdx.x * 256 + threadIdx.x + 1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;
+        av4[i] = ((double)(z >> 11) * 0x1.0p-52 - 1.0) * a;
+        z += 0x9E3779B97F4A7C15ull;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;
+        bv4[i] = ((double)(z >> 11) * 0x1.0p-52 - 1.0) + b;
+    }
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
     const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int u = 0; u < 4; ++u)
 #pragma unroll
-            for (int i = 0; i < ACC; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[i], 0, 0, 0);
+            for (int i = 0; i < ACC; ++i)
+                acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(av4[(u + i) & 3], bv4[u], acc[i], 0, 0, 0);
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
     const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
@@ -100,6 +147,8 @@ int main() {
     run("fma acc8", fma_loop<8>, 2.0 * 8 * 8, 4, 10000, 0.05);
     run("fma acc8", fma_loop<8>, 2.0 * 8 * 8, 4, 10000, 2.0);
     run("fma acc8", fma_loop<8>, 2.0 * 8 * 8, 2, 10000, 2.0);
+    run("fma rand", fma_loop_random<8>, 2.0 * 8 * 8, 4, 10000, 2.0);
+    run("fma rand", fma_loop_random<8>, 2.0 * 8 * 8, 2, 10000, 2.0);
     // one MFMA = 16*16*4*2 flops per wave = 32 flops per lane
     run("mfma acc4", mfma_loop<4>, 32.0 * 4 * 4, 1, 10000, 2.0);
     run("mfma acc4", mfma_loop<4>, 32.0 * 4 * 4, 2, 10000, 2.0);
