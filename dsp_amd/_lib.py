@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libdspx.so")
+# DSPX_LIB selects another build of the same library (kernel experiments); it is never a fallback
+LIB_PATH = os.environ.get("DSPX_LIB") or os.path.join(_HERE, "lib", "libdspx.so")
 
 DSPX_OK = 0
 DSPX_FIR_FMA = 0

@@ -124,9 +124,10 @@ __global__ __launch_bounds__(kBlock) void fir_f64_kernel(const double* __restric
         const int npairs = (kSlots - qlo) / 2;
         const long long g_lo = tile_start - j0 - kHalo + qlo;        // sample held by slot qlo
         if (j0 > 0) __syncthreads();                                  // readers of the previous stage are done
-        double2 v[kStageIters];
+        double2* stage = lds + pair_of(qlo) + stage_pair;
         if (g_lo >= 0 && g_lo + (kSlots - qlo) <= n) {  // interior tile (workgroup-uniform): no edge tests
             const double* __restrict__ src = xc + g_lo;
+            double2 v[kStageIters];
 #pragma unroll
             for (int i = 0; i < kStageIters; ++i) {
                 const int pi = tid + i * kBlock;
@@ -137,19 +138,18 @@ __global__ __launch_bounds__(kBlock) void fir_f64_kernel(const double* __restric
                         v[i] = make_double2(src[2 * pi], src[2 * pi + 1]);
                 }
             }
-        } else {
 #pragma unroll
             for (int i = 0; i < kStageIters; ++i) {
-                const int pi = tid + i * kBlock;
-                if (i < kStageIters - 1 || pi < npairs)
-                    v[i] = make_double2(sample_at(xc, hc, g_lo + 2 * pi, n, ntaps),
-                                        sample_at(xc, hc, g_lo + 2 * pi + 1, n, ntaps));
+                if (i < kStageIters - 1 || tid + i * kBlock < npairs) stage[i * pair_of(2 * kBlock)] = v[i];
             }
-        }
-        double2* stage = lds + pair_of(qlo) + stage_pair;
-#pragma unroll
-        for (int i = 0; i < kStageIters; ++i) {
-            if (i < kStageIters - 1 || tid + i * kBlock < npairs) stage[i * pair_of(2 * kBlock)] = v[i];
+        } else {  // first / last tiles of a channel: every sample is range-checked (kept small, not fast)
+#pragma unroll 1
+            for (int i = 0; i < kStageIters; ++i) {
+                const int pi = tid + i * kBlock;
+                if (pi < npairs)
+                    stage[i * pair_of(2 * kBlock)] = make_double2(sample_at(xc, hc, g_lo + 2 * pi, n, ntaps),
+                                                                  sample_at(xc, hc, g_lo + 2 * pi + 1, n, ntaps));
+            }
         }
         __syncthreads();
 

@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Quick device-resident timing of the FIR kernel over several workloads (development aid).
+   python tools/qb.py [name ...]     names: b255 l101 l4095 b255s b31 b63 b1023"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+import dsp_amd
+
+W = {"b255": (4096, 1 << 20, 255), "l101": (1, 1 << 28, 101), "l4095": (1, 1 << 26, 4095), "b255s": (256, 1 << 20, 255),
+     "b31": (1024, 1 << 20, 31), "b63": (1024, 1 << 20, 63), "b1023": (256, 1 << 20, 1023), "b101": (2048, 1 << 20, 101), "b256": (4096, 1 << 20, 256), "b240": (4096, 1 << 20, 240), "b512": (2048, 1 << 20, 512),
+     "b96": (2048, 1 << 20, 96), "b112": (2048, 1 << 20, 112)}
+names = sys.argv[1:] or ["b255", "l101", "l4095"]
+for nm in names:
+    nchan, n, nt = W[nm]
+    taps = torch.from_numpy(dsp_amd.firwin(nt, 0.25)).cuda()
+    x = torch.empty((nchan, n), dtype=torch.float64, device="cuda")
+    y = torch.empty_like(x)
+    dsp_amd.fill_splitmix(x)
+    for _ in range(3):
+        dsp_amd.fir_device(taps, x, out=y)
+    torch.cuda.synchronize()
+    reps = max(5, int(0.6 / (nchan * n * nt * 2 / 50e12 + 1e-4)))
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        dsp_amd.fir_device(taps, x, out=y)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    gs = nchan * n / ms / 1e6
+    print(f"{nm:6s} taps={nt:5d} {ms:9.3f} ms  {gs:8.2f} GS/s  {gs * 2 * nt / 1e3:6.2f} TFLOP/s ({gs * 2 * nt / 786:5.1f}% fp64)  "
+          f"{gs * 16 / 1e3:5.2f} TB/s ({gs * 16 / 80:5.1f}% hbm)", flush=True)
+    del x, y
