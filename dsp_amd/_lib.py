@@ -37,6 +37,20 @@ SIGNATURES = {
     "dspx_fir_plan": (C.c_long, [C.c_size_t, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t]),
     "dspx_fir_f64_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
                                    C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_uint, C.c_void_p]),
+    "dspx_integrate_wavelet_morlet_f64": (C.c_int, [C.c_size_t, C.c_double, C.c_double, C.c_void_p, C.c_void_p]),
+    "dspx_cwt_f64": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p,
+                               C.c_size_t, C.c_void_p, C.c_uint]),
+    "dspx_cwt_f64_multi": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p,
+                                     C.c_size_t, C.c_void_p, C.c_int, C.c_uint]),
+    "dspx_cwt_plan": (C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p,
+                                C.c_void_p]),
+    "dspx_cwt_bank_create": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                       C.c_void_p]),
+    "dspx_cwt_bank_rows": (C.c_size_t, [C.c_void_p]),
+    "dspx_cwt_bank_total_taps": (C.c_size_t, [C.c_void_p]),
+    "dspx_cwt_bank_apply_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_uint,
+                                          C.c_void_p]),
+    "dspx_cwt_bank_destroy": (None, [C.c_void_p]),
     "dspx_fill_splitmix_f64_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_uint64, C.c_uint64, C.c_void_p]),
     "dspx_checksum_f64_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_uint64, C.c_void_p, C.c_void_p]),
 }

@@ -59,6 +59,74 @@ def lfilter_multi(b, x, ngpus: int = 0, exact: bool = False) -> np.ndarray:
     return y.reshape(x.shape)
 
 
+def integrate_wavelet(precision: int = 10, lower: float = -8.0, upper: float = 8.0):
+    """dsp::integrate_wavelet(MORLET, precision, lower, upper) -> (psi, x), host arithmetic."""
+    n = 1 << precision if 0 <= precision < 40 else 1
+    psi, x = np.empty(n), np.empty(n)
+    check(lib().dspx_integrate_wavelet_morlet_f64(precision, lower, upper, psi.ctypes.data, x.ctypes.data))
+    return psi, x
+
+
+def cwt(signal, scales, psi, wx, exact: bool = False, ngpus=None) -> np.ndarray:
+    """dsp::cwt(signal, scales, psi, x) for host arrays -> (len(scales), len(signal)), rows by ascending scale."""
+    signal, scales, psi, wx = _np_f64(signal), _np_f64(np.atleast_1d(scales)), _np_f64(psi), _np_f64(wx)
+    out = np.empty((scales.size, signal.size), dtype=np.float64)
+    if ngpus is None:
+        rc = lib().dspx_cwt_f64(signal.ctypes.data, signal.size, scales.ctypes.data, scales.size, psi.ctypes.data,
+                                psi.size, wx.ctypes.data, wx.size, out.ctypes.data, _flags(exact))
+    else:
+        rc = lib().dspx_cwt_f64_multi(signal.ctypes.data, signal.size, scales.ctypes.data, scales.size,
+                                      psi.ctypes.data, psi.size, wx.ctypes.data, wx.size, out.ctypes.data, int(ngpus),
+                                      _flags(exact))
+    check(rc)
+    return out
+
+
+def cwt_plan(scales, npsi: int, wx, ngpus: int):
+    """(device, ntaps) of every sorted scale, as dspx_cwt_f64_multi would assign them."""
+    scales, wx = _np_f64(np.atleast_1d(scales)), _np_f64(wx)
+    dev = np.zeros(scales.size, dtype=np.int32)
+    nt = np.zeros(scales.size, dtype=np.uint64)
+    check(lib().dspx_cwt_plan(scales.ctypes.data, scales.size, npsi, wx.ctypes.data, wx.size, ngpus, dev.ctypes.data,
+                              nt.ctypes.data))
+    return dev.tolist(), nt.astype(np.int64).tolist()
+
+
+class CwtBank:
+    """Per-scale tables of dsp::cwt kept on the current device (dspx_cwt_bank_*)."""
+
+    def __init__(self, scales, psi, wx):
+        scales, psi, wx = _np_f64(np.atleast_1d(scales)), _np_f64(psi), _np_f64(wx)
+        h = C.c_void_p()
+        check(lib().dspx_cwt_bank_create(scales.ctypes.data, scales.size, psi.ctypes.data, psi.size, wx.ctypes.data,
+                                         wx.size, C.byref(h)))
+        self._h = h
+        self.rows = int(lib().dspx_cwt_bank_rows(h))
+        self.total_taps = int(lib().dspx_cwt_bank_total_taps(h))
+
+    def apply(self, signal, out=None, exact: bool = False):
+        import torch
+
+        assert signal.is_cuda and signal.dtype == torch.float64 and signal.dim() == 1 and signal.is_contiguous()
+        if out is None:
+            out = torch.empty((self.rows, signal.numel()), dtype=torch.float64, device=signal.device)
+        assert out.shape == (self.rows, signal.numel()) and out.stride(1) == 1
+        check(lib().dspx_cwt_bank_apply_dev(self._h, signal.data_ptr(), signal.numel(), out.data_ptr(), out.stride(0),
+                                            _flags(exact), _stream_ptr()))
+        return out
+
+    def close(self):
+        if self._h:
+            lib().dspx_cwt_bank_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def fir_plan(nchan: int, n: int, ngpus: int):
     """The multi-GPU sharding plan as a list of (device, chan, nchan, start, len) tuples."""
     total = lib().dspx_fir_plan(nchan, n, ngpus, None, 0)

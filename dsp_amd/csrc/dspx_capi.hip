@@ -14,9 +14,10 @@
 
 #include "dsp.hpp"
 #include "dspx.h"
+#include "dspx_common.h"
 #include "fir_kernels.h"
 
-namespace {
+namespace dspx {
 
 thread_local std::string g_last_error;
 
@@ -30,17 +31,15 @@ int fail(int code, const char* fmt, ...) {
     return code;
 }
 
-#define DSPX_HIP(call)                                                                              \
-    do {                                                                                            \
-        hipError_t e_ = (call);                                                                     \
-        if (e_ != hipSuccess)                                                                       \
-            return fail(e_ == hipErrorOutOfMemory ? DSPX_ERR_NOMEM : DSPX_ERR_HIP, "%s: %s", #call, \
-                        hipGetErrorString(e_));                                                     \
-    } while (0)
+}  // namespace dspx
+
+namespace {
+
+using dspx::aligned16;
+using dspx::fail;
+using dspx::g_last_error;
 
 constexpr unsigned long long kMaxGrid = 0x7fffffffull;  // workgroups per launch
-
-bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 bool ranges_overlap(const void* a, size_t abytes, const void* b, size_t bbytes) {
     const uintptr_t a0 = reinterpret_cast<uintptr_t>(a), b0 = reinterpret_cast<uintptr_t>(b);
@@ -254,6 +253,7 @@ const char* dspx_status_string(int status) {
     case DSPX_ERR_NO_DEVICE: return "no usable device";
     case DSPX_ERR_HIP: return "HIP runtime error";
     case DSPX_ERR_NOMEM: return "out of device memory";
+    case DSPX_ERR_DOMAIN: return "value outside the supported domain";
     default: return "unknown status";
     }
 }

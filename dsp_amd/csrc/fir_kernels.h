@@ -24,10 +24,26 @@ inline void set_tile_divider(FirShape& s) {
     s.div_magic = ((1ull << s.div_shift) + s.tiles_per_chan - 1) / s.tiles_per_chan;
 }
 
-int fir_tile();  // outputs per workgroup
+// One row of a filter bank (bank mode of the kernel): its taps, where its results go, the factor
+// applied to the first difference of its convolution, and how far its output is advanced.
+struct BankRow {
+    unsigned long long taps_off;  // offset of the row's taps in the packed tap buffer
+    unsigned long long out_off;   // row of the output buffer that receives the results (times FirShape::y_stride)
+    double scale;
+    int ntaps;
+    int advance;
+};
+
+int fir_tile();         // outputs per workgroup
+int fir_bank_stride();  // outputs per workgroup in bank mode
 
 hipError_t launch_fir_f64(const double* taps, const double* x, const double* hist, double* y, const FirShape& shape,
                           bool exact, bool vec2, hipStream_t stream);
+// Bank mode: shape.n = length of the single input and of every output row, shape.y_stride = elements
+// between output rows, shape.tiles_per_chan = ceil(n / fir_bank_stride()), shape.total_tiles =
+// rows * tiles_per_chan; the other strides and ntaps are unused.
+hipError_t launch_fir_bank_f64(const double* taps, const BankRow* bank, const double* x, double* y,
+                               const FirShape& shape, bool exact, bool vec2, hipStream_t stream);
 hipError_t launch_fill_splitmix(double* x, unsigned long long n, unsigned long long seed, unsigned long long offset,
                                 hipStream_t stream);
 hipError_t launch_checksum(const double* y, unsigned long long n, unsigned long long offset, unsigned long long* out,

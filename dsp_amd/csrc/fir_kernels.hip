@@ -39,6 +39,7 @@ constexpr int kHalo = kStageTaps;         // window slots in front of the tile
 constexpr int kSlots = kHalo + kTile;     // window slots per stage
 constexpr int kLdsPairs = (kSlots + kSlots / 4) / 2;             // 16-byte pairs in the padded image
 constexpr int kStageIters = (kSlots / 2 + kBlock - 1) / kBlock;  // 16-byte loads per thread per stage
+constexpr int kBankStride = kTile - kR;   // outputs per tile in bank mode (the tile's last thread only supplies c[i+1])
 
 static_assert(kR == 8 && kGroup == 16, "the window indexing below assumes 8 outputs per thread, 16-tap groups");
 static_assert(kHalo % 16 == 0 && kTile % 8 == 0 && kStageTaps % kGroup == 0, "padding groups must align");
@@ -87,11 +88,16 @@ __device__ __forceinline__ void load_window(const double2* top, int g, double (&
     asm volatile("" ::"v"(W[kWin - 1]));
 }
 
-template <bool EXACT, bool VEC2>
+// BANK = false: nchan independent channels, one tap vector (the lfilter path).
+// BANK = true: one input, a bank of tap vectors of different lengths (the wavelet path, reference
+// dsp.hpp:1136-1217): row r computes c[t] = sum_k taps_r[k] * x[t + advance_r - k] with zeros outside
+// [0, n), and stores (c[i+1] - c[i]) * scale_r for i < n.  A tile still computes 2048 values of c but
+// advances by kBankStride = 2040 outputs, so that the c[i+1] of its last output is its own.
+template <bool EXACT, bool VEC2, bool BANK>
 __global__ __launch_bounds__(kBlock) void fir_f64_kernel(const double* __restrict__ taps,
                                                           const double* __restrict__ x,
                                                           const double* __restrict__ hist, double* __restrict__ y,
-                                                          FirShape s) {
+                                                          const BankRow* __restrict__ bank, FirShape s) {
     __shared__ double2 lds[kLdsPairs];
     const int tid = threadIdx.x;
 
@@ -103,11 +109,33 @@ __global__ __launch_bounds__(kBlock) void fir_f64_kernel(const double* __restric
     const unsigned tile_id = (grp < r8 ? grp * (q8 + 1) : r8 * (q8 + 1) + (grp - r8) * q8) + k;
     // tile_id / tiles_per_chan by multiplication (exact for tile_id < 2^31)
     const unsigned chan = (unsigned)(((unsigned long long)tile_id * s.div_magic) >> s.div_shift);
-    const long long tile_start = (long long)(tile_id - chan * s.tiles_per_chan) * kTile;
-    const double* __restrict__ xc = x + (unsigned long long)chan * s.x_stride;
-    const double* __restrict__ hc = hist ? hist + (unsigned long long)chan * s.hist_stride : nullptr;
+    const unsigned tile = tile_id - chan * s.tiles_per_chan;
     const long long n = s.n;
-    const int ntaps = s.ntaps;
+    long long tile_start, pos0;  // first output of the tile; input position its tap 0 multiplies
+    int ntaps;
+    double post = 1.0;
+    const double* __restrict__ xc;
+    const double* __restrict__ hc;
+    const double* __restrict__ tapsc;
+    double* __restrict__ yrow;
+    if constexpr (BANK) {
+        const BankRow row = bank[chan];
+        tile_start = (long long)tile * kBankStride;
+        pos0 = tile_start + row.advance;
+        ntaps = row.ntaps;
+        post = row.scale;
+        xc = x, hc = nullptr;
+        tapsc = taps + row.taps_off;
+        yrow = y + row.out_off * s.y_stride;
+    } else {
+        tile_start = (long long)tile * kTile;
+        pos0 = tile_start;
+        ntaps = s.ntaps;
+        xc = x + (unsigned long long)chan * s.x_stride;
+        hc = hist ? hist + (unsigned long long)chan * s.hist_stride : nullptr;
+        tapsc = taps;
+        yrow = y + (unsigned long long)chan * s.y_stride;
+    }
     const int stage_pair = tid + (tid >> 2);  // pair_of(2*tid): where this thread's staged pairs go
 
     double acc[kR];
@@ -119,10 +147,10 @@ __global__ __launch_bounds__(kBlock) void fir_f64_kernel(const double* __restric
         const int ngroups = S / kGroup;
         const int rem = S % kGroup;
 
-        // ---- stage the window: slot q <- sample tile_start - j0 - kHalo + q, for q >= qlo ----
+        // ---- stage the window: slot q <- sample pos0 - j0 - kHalo + q, for q >= qlo ----
         const int qlo = kHalo - kGroup * (ngroups + (rem ? 1 : 0));  // lowest slot the window loads touch
         const int npairs = (kSlots - qlo) / 2;
-        const long long g_lo = tile_start - j0 - kHalo + qlo;        // sample held by slot qlo
+        const long long g_lo = pos0 - j0 - kHalo + qlo;              // sample held by slot qlo
         if (j0 > 0) __syncthreads();                                  // readers of the previous stage are done
         double2* stage = lds + pair_of(qlo) + stage_pair;
         if (g_lo >= 0 && g_lo + (kSlots - qlo) <= n) {  // interior tile (workgroup-uniform): no edge tests
@@ -154,7 +182,7 @@ __global__ __launch_bounds__(kBlock) void fir_f64_kernel(const double* __restric
         __syncthreads();
 
         // ---- accumulate the stage's taps, 16 per group ----
-        const double* __restrict__ tp = taps + j0;
+        const double* __restrict__ tp = tapsc + j0;
         const double2* top = lds + pair_of(kHalo + 6) + 5 * tid;
         for (int g = 0; g < ngroups; ++g) {
             double W[kWin], bt[kGroup];
@@ -190,25 +218,47 @@ __global__ __launch_bounds__(kBlock) void fir_f64_kernel(const double* __restric
 #pragma unroll
     for (int r = 0; r < kR; r += 2) lds[5 * tid + r / 2] = make_double2(acc[r], acc[r + 1]);
     __syncthreads();
-    double* __restrict__ yt = y + (unsigned long long)chan * s.y_stride + tile_start;
+    double* __restrict__ yt = yrow + tile_start;
     const double2* back = lds + stage_pair;
-    const long long left = n - tile_start;  // outputs of this channel from tile_start on
+    const long long left = n - tile_start;  // outputs of this row from tile_start on
+    if constexpr (BANK) {
 #pragma unroll
-    for (int i = 0; i < kTile / 2 / kBlock; ++i) {
-        const int pi = tid + i * kBlock;
-        const double2 o = back[i * pair_of(2 * kBlock)];
-        if (left >= kTile) {  // full tile (workgroup-uniform)
-            if constexpr (VEC2)
-                reinterpret_cast<double2*>(yt)[pi] = o;
-            else
-                yt[2 * pi] = o.x, yt[2 * pi + 1] = o.y;
-        } else if (2 * pi + 1 < left) {
-            if constexpr (VEC2)
-                reinterpret_cast<double2*>(yt)[pi] = o;
-            else
-                yt[2 * pi] = o.x, yt[2 * pi + 1] = o.y;
-        } else if (2 * pi < left) {
-            yt[2 * pi] = o.x;
+        for (int i = 0; i < kTile / 2 / kBlock; ++i) {
+            const int pi = tid + i * kBlock, pn = pi + 1;
+            const double2 c01 = back[i * pair_of(2 * kBlock)];
+            const double2 c23 = lds[pn + (pn >> 2)];  // pair_of(2 * pn)
+            // first difference times the row's factor, as two separately rounded operations
+            // (reference dsp.hpp:1186-1191)
+            const double2 o = make_double2((c01.y - c01.x) * post, (c23.x - c01.y) * post);
+            if (2 * pi < kBankStride) {
+                if (2 * pi + 1 < left) {
+                    if constexpr (VEC2)
+                        reinterpret_cast<double2*>(yt)[pi] = o;
+                    else
+                        yt[2 * pi] = o.x, yt[2 * pi + 1] = o.y;
+                } else if (2 * pi < left) {
+                    yt[2 * pi] = o.x;
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < kTile / 2 / kBlock; ++i) {
+            const int pi = tid + i * kBlock;
+            const double2 o = back[i * pair_of(2 * kBlock)];
+            if (left >= kTile) {  // full tile (workgroup-uniform)
+                if constexpr (VEC2)
+                    reinterpret_cast<double2*>(yt)[pi] = o;
+                else
+                    yt[2 * pi] = o.x, yt[2 * pi + 1] = o.y;
+            } else if (2 * pi + 1 < left) {
+                if constexpr (VEC2)
+                    reinterpret_cast<double2*>(yt)[pi] = o;
+                else
+                    yt[2 * pi] = o.x, yt[2 * pi + 1] = o.y;
+            } else if (2 * pi < left) {
+                yt[2 * pi] = o.x;
+            }
         }
     }
 }
@@ -248,21 +298,42 @@ __global__ __launch_bounds__(256) void checksum_kernel(const double* __restrict_
 }  // namespace
 
 int fir_tile() { return kTile; }
+int fir_bank_stride() { return kBankStride; }
 
 hipError_t launch_fir_f64(const double* taps, const double* x, const double* hist, double* y, const FirShape& shape,
                           bool exact, bool vec2, hipStream_t stream) {
     if (shape.total_tiles == 0) return hipSuccess;
     const dim3 grid(shape.total_tiles), block(kBlock);
+    const BankRow* none = nullptr;
     if (exact) {
         if (vec2)
-            hipLaunchKernelGGL((fir_f64_kernel<true, true>), grid, block, 0, stream, taps, x, hist, y, shape);
+            hipLaunchKernelGGL((fir_f64_kernel<true, true, false>), grid, block, 0, stream, taps, x, hist, y, none, shape);
         else
-            hipLaunchKernelGGL((fir_f64_kernel<true, false>), grid, block, 0, stream, taps, x, hist, y, shape);
+            hipLaunchKernelGGL((fir_f64_kernel<true, false, false>), grid, block, 0, stream, taps, x, hist, y, none, shape);
     } else {
         if (vec2)
-            hipLaunchKernelGGL((fir_f64_kernel<false, true>), grid, block, 0, stream, taps, x, hist, y, shape);
+            hipLaunchKernelGGL((fir_f64_kernel<false, true, false>), grid, block, 0, stream, taps, x, hist, y, none, shape);
         else
-            hipLaunchKernelGGL((fir_f64_kernel<false, false>), grid, block, 0, stream, taps, x, hist, y, shape);
+            hipLaunchKernelGGL((fir_f64_kernel<false, false, false>), grid, block, 0, stream, taps, x, hist, y, none, shape);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_fir_bank_f64(const double* taps, const BankRow* bank, const double* x, double* y,
+                               const FirShape& shape, bool exact, bool vec2, hipStream_t stream) {
+    if (shape.total_tiles == 0) return hipSuccess;
+    const dim3 grid(shape.total_tiles), block(kBlock);
+    const double* none = nullptr;
+    if (exact) {
+        if (vec2)
+            hipLaunchKernelGGL((fir_f64_kernel<true, true, true>), grid, block, 0, stream, taps, x, none, y, bank, shape);
+        else
+            hipLaunchKernelGGL((fir_f64_kernel<true, false, true>), grid, block, 0, stream, taps, x, none, y, bank, shape);
+    } else {
+        if (vec2)
+            hipLaunchKernelGGL((fir_f64_kernel<false, true, true>), grid, block, 0, stream, taps, x, none, y, bank, shape);
+        else
+            hipLaunchKernelGGL((fir_f64_kernel<false, false, true>), grid, block, 0, stream, taps, x, none, y, bank, shape);
     }
     return hipGetLastError();
 }

@@ -4,6 +4,8 @@
 // reference header for:
 //     dsp::firwin        (reference dsp/include/dsp.hpp:190-311)   host tap design
 //     dsp::lfilter       (reference dsp.hpp:333-396)               FIR filtering on the GPU
+//     dsp::integrate_wavelet (reference dsp.hpp:934-985)           host wavelet table
+//     dsp::cwt           (reference dsp.hpp:987-1239)              wavelet bank on the same GPU kernel
 // plus what they depend on: dsp::constants (dsp.hpp:34-53), dsp::math::sinc
 // (dsp.hpp:60-67), dsp::hamming_window (dsp.hpp:74-115), dsp::types::window_t
 // (dsp.hpp:119-121), dsp::lfilter_ctx_t (dsp.hpp:333).
@@ -20,6 +22,7 @@
 // Requires C++20.  Link with -ldspx.
 #pragma once
 
+#include <algorithm>
 #include <array>
 #include <cmath>
 #include <concepts>
@@ -28,6 +31,7 @@
 #include <stdexcept>
 #include <string>
 #include <type_traits>
+#include <utility>
 #include <vector>
 
 #include "dspx.h"
@@ -241,6 +245,103 @@ template <typename T = double, typename Container_1, typename Container_2>
     requires std::floating_point<T> && indexable_of<Container_1, T> && indexable_of<Container_2, T>
 std::vector<T> lfilter(const Container_1& numerators, T denominator, const Container_2& x) {
     return lfilter<T>(numerators, std::array<T, 1>{denominator}, x);
+}
+
+namespace types {
+
+enum class cwt_wavelet_t {
+    MORLET,
+};
+
+}  // namespace types
+
+// Samples the wavelet on 2^percision points of [lower, upper] and replaces it by its running
+// integral (cumulative sum times the grid step).  Returns {psi, x}.
+template <std::floating_point T = double>
+std::pair<std::vector<T>, std::vector<T>> integrate_wavelet(cwt_wavelet_t wavelet, std::size_t percision = 10,
+                                                            T lower = -8.0, T upper = 8.0) {
+    if (percision <= 2 || percision >= sizeof(std::size_t) * 8) [[unlikely]]
+        throw std::invalid_argument("The percision must be greater than 2 or less than the number of bits in size_t.");
+    if (lower >= upper) [[unlikely]] throw std::invalid_argument("The lower must be less than upper.");
+    if (wavelet != cwt_wavelet_t::MORLET) [[unlikely]] throw std::invalid_argument("Unsupported wavelet type.");
+
+    const std::size_t count = std::size_t(1) << percision;
+    std::vector<T> psi(count), grid(count);
+    const T width = upper - lower;
+    const T last = static_cast<T>(count - 1);
+    for (std::size_t i = 0; i < count; ++i) {
+        const T t = lower + (width * (static_cast<T>(i) / last));
+        grid[i] = t;
+        psi[i] = std::exp(static_cast<T>(-0.5) * t * t) * std::cos(static_cast<T>(5.0) * t);  // Morlet
+    }
+    const T step = grid[1] - grid[0];
+    T running = 0.0;
+    for (auto& p : psi) {
+        running += p;
+        p = running * step;
+    }
+    return {std::move(psi), std::move(grid)};
+}
+
+// Scales sorted ascending with their -sqrt, result buffer and its shape {scales, samples}.  The
+// scratch vectors of the reference's context are kept as members for source compatibility; the
+// GPU path does not use them.
+template <typename T = double, typename Container = std::vector<T>> struct cwt_ctx_t {
+    cwt_ctx_t() = default;
+    cwt_ctx_t(const Container& s) : scales(s) {
+        std::sort(scales.begin(), scales.end());
+        negtive_sqrt_scales.reserve(scales.size());
+        for (const auto& v : scales) negtive_sqrt_scales.push_back(static_cast<T>(-std::sqrt(v)));
+    }
+
+    Container scales;
+    std::vector<T> negtive_sqrt_scales;
+
+    std::vector<std::size_t> psi_arange;
+    std::vector<std::size_t> psi_indices;
+    std::vector<T> coefficients;
+
+    std::vector<T> result;
+    std::vector<std::size_t> shape;
+};
+
+// Continuous wavelet transform of `signal` for every scale of ctx: ctx.result holds one row of
+// signal.size() coefficients per (sorted) scale, ctx.shape = {scales, samples}.
+template <typename T = double, typename P = double, typename Container_1, typename Container_2, typename Container_3,
+          typename Container_4>
+    requires std::floating_point<T> && std::floating_point<P> && indexable_of<Container_1, P> &&
+             indexable_of<Container_2, T> && indexable_of<Container_3, T> && indexable_of<Container_4, T>
+void cwt(cwt_ctx_t<T, Container_1>& ctx, const Container_2& signal, const Container_3& wavelet_psi,
+         const Container_4& wavelet_x) {
+    static_assert(std::is_same_v<T, double> && std::is_same_v<P, double> &&
+                    std::is_same_v<typename Container_2::value_type, double> &&
+                    std::is_same_v<typename Container_3::value_type, double> &&
+                    std::is_same_v<typename Container_4::value_type, double>,
+                  "dsp::cwt (MI355X): only T = P = double over containers of double is implemented");
+    std::vector<double> scales(ctx.scales.size());
+    for (std::size_t i = 0; i < scales.size(); ++i) scales[i] = static_cast<double>(ctx.scales[i]);
+    const detail::double_view<Container_2> sig(signal);
+    const detail::double_view<Container_3> psi(wavelet_psi);
+    const detail::double_view<Container_4> grid(wavelet_x);
+    const std::size_t wanted = scales.size() * sig.size();
+    std::vector<T> out(wanted);
+    const int rc = dspx_cwt_f64(sig.data(), sig.size(), scales.data(), scales.size(), psi.data(), psi.size(),
+                                grid.data(), grid.size(), out.data(), DSPX_FIR_FMA);
+    if (rc == DSPX_ERR_INVALID) throw std::invalid_argument(dspx_last_error());
+    if (rc != DSPX_OK) throw std::runtime_error(dspx_last_error());
+    ctx.result = std::move(out);
+    ctx.shape = {scales.size(), sig.size()};
+}
+
+template <typename T = double, typename P = double, typename Container_1, typename Container_2, typename Container_3,
+          typename Container_4>
+    requires std::floating_point<T> && std::floating_point<P> && indexable_of<Container_1, T> &&
+             indexable_of<Container_2, T> && indexable_of<Container_3, T> && indexable_of<Container_4, T>
+std::vector<T> cwt(const Container_1& signal, const Container_2& scales, const Container_3& wavelet_psi,
+                   const Container_4& wavelet_x) {
+    cwt_ctx_t<T, Container_2> ctx(scales);
+    cwt<T, P>(ctx, signal, wavelet_psi, wavelet_x);
+    return std::move(ctx.result);
 }
 
 }  // namespace dsp

@@ -32,7 +32,8 @@ typedef enum dspx_status {
     DSPX_ERR_INVALID = -1,   /* bad pointer / size / stride / overlapping buffers */
     DSPX_ERR_NO_DEVICE = -2, /* no usable gfx950 device */
     DSPX_ERR_HIP = -3,       /* a HIP runtime call failed; see dspx_last_error() */
-    DSPX_ERR_NOMEM = -4      /* device allocation failed */
+    DSPX_ERR_NOMEM = -4,     /* device allocation failed */
+    DSPX_ERR_DOMAIN = -5     /* where the reference throws std::runtime_error (e.g. a wavelet scale too large) */
 } dspx_status;
 
 /* Arithmetic mode of the filter kernels (the `flags` argument). */
@@ -104,6 +105,45 @@ DSPX_API long dspx_fir_plan(size_t nchan, size_t n, int ngpus, dspx_piece* out, 
 DSPX_API int dspx_fir_f64_dev(const double* d_taps, size_t ntaps, const double* d_x, size_t x_stride, const double* d_hist,
                      size_t hist_stride, double* d_y, size_t y_stride, size_t nchan, size_t n, unsigned flags,
                      void* stream);
+
+/* ---- wavelet bank on the FIR kernel ---------------------------------------------------
+ * integrate_wavelet<double>(MORLET, precision, lower, upper)   dsp.hpp:934-985   (host arithmetic)
+ * psi and x each hold 2^precision doubles. */
+DSPX_API int dspx_integrate_wavelet_morlet_f64(size_t precision, double lower, double upper, double* psi, double* x);
+
+/* cwt(signal, scales, wavelet_psi, wavelet_x)                   dsp.hpp:1040-1239
+ * `scales` may come in any order; like cwt_ctx_t's constructor (dsp.hpp:1008-1015) the call sorts
+ * them ascending, and `result` (nscales x n, row-major, host memory) has one row per sorted scale.
+ * Host side (same arithmetic as the reference): per scale the index table
+ * floor(j / max(scale*x_step, EPS)) (dsp.hpp:1141-1150), the gathered, reversed wavelet as a tap
+ * vector, -sqrt(scale), and the centre-crop offset floor((L-2)/2) (dsp.hpp:1194-1216).
+ * GPU side: row r is the FIR of the zero-extended signal with its L_r taps, then
+ * (c[i+1] - c[i]) * -sqrt(scale) (dsp.hpp:1185-1191), cropped -- all rows in one launch.
+ * Errors: where the reference throws std::invalid_argument -> DSPX_ERR_INVALID; where it throws
+ * std::runtime_error ("Selected scale is too large/small", no scales) -> DSPX_ERR_DOMAIN; the
+ * reference's message is in dspx_last_error().  A table of a single tap, on which the reference
+ * fails an assertion (dsp.hpp:1193), is reported as "too small". */
+DSPX_API int dspx_cwt_f64(const double* signal, size_t n, const double* scales, size_t nscales, const double* psi,
+                          size_t npsi, const double* wx, size_t nx, double* result, unsigned flags);
+/* The same, with the scales sharded over the first `ngpus` devices (0 = all), balanced by the sum of
+ * their tap counts; every device reads the whole signal and produces whole rows (no exchange). */
+DSPX_API int dspx_cwt_f64_multi(const double* signal, size_t n, const double* scales, size_t nscales,
+                                const double* psi, size_t npsi, const double* wx, size_t nx, double* result, int ngpus,
+                                unsigned flags);
+/* Which device dspx_cwt_f64_multi gives each sorted scale to, and its tap count (no GPU needed). */
+DSPX_API int dspx_cwt_plan(const double* scales, size_t nscales, size_t npsi, const double* wx, size_t nx, int ngpus,
+                           int* device_of_row, size_t* ntaps_of_row);
+
+/* Device-resident use: the per-scale tables are built once and kept on the current device. */
+typedef struct dspx_cwt_bank dspx_cwt_bank;
+DSPX_API int dspx_cwt_bank_create(const double* scales, size_t nscales, const double* psi, size_t npsi,
+                                  const double* wx, size_t nx, dspx_cwt_bank** bank);
+DSPX_API size_t dspx_cwt_bank_rows(const dspx_cwt_bank* bank);
+DSPX_API size_t dspx_cwt_bank_total_taps(const dspx_cwt_bank* bank);
+/* d_result row r (r-th smallest scale) starts at d_result + r*row_stride; row_stride >= n. */
+DSPX_API int dspx_cwt_bank_apply_dev(const dspx_cwt_bank* bank, const double* d_signal, size_t n, double* d_result,
+                                     size_t row_stride, unsigned flags, void* stream);
+DSPX_API void dspx_cwt_bank_destroy(dspx_cwt_bank* bank);
 
 /* ---- deterministic synthetic data and checksums (benchmark / parity support) -----
  * d_x[i] = ((mix64(seed + (offset+i+1)*0x9E3779B97F4A7C15) >> 11) * 2^-52) - 1.0,

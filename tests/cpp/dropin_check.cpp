@@ -7,6 +7,8 @@
 //   dropin_check readme                               firwin(100, 0.5) + lfilter over sin(n), n < 1024
 //   dropin_check filter <numtaps> <cutoff>  < samples lfilter(firwin(...), 1.0, x), x from stdin
 //   dropin_check api                                  overloads, ctx reuse, containers, error behaviour
+//   dropin_check cwt <nscales>              < samples integrate_wavelet(MORLET, 10) + cwt over integer scales 1..nscales
+//   dropin_check wavelet <precision>                  integrate_wavelet only (no GPU needed)
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -69,6 +71,31 @@ int main(int argc, char** argv) {
         dump("y", r);
         return 0;
     }
+    if (mode == "wavelet" && argc == 3) {
+        auto [psi, x] = integrate_wavelet<double>(cwt_wavelet_t::MORLET, std::strtoul(argv[2], nullptr, 10));
+        dump("psi", psi);
+        dump("x", x);
+        return 0;
+    }
+    if (mode == "cwt" && argc == 3) {  // the call shape of the reference's README.md:44-54 and test_cwt (dsp.hpp:2764-2766)
+        std::vector<double> data;
+        std::string tok;
+        while (std::cin >> tok) data.push_back(std::strtod(tok.c_str(), nullptr));
+        std::vector<int> scales(std::strtoul(argv[2], nullptr, 10));
+        for (size_t i = 0; i < scales.size(); ++i) scales[i] = static_cast<int>(i) + 1;
+        auto [psi, x] = integrate_wavelet<double>(cwt_wavelet_t::MORLET, 10);
+        auto r = cwt<double>(data, scales, psi, x);
+        dump("cwt", r);
+        // the ctx overload gives the same rows and reports the shape
+        std::vector<double> fscales(scales.begin(), scales.end());
+        cwt_ctx_t<double, std::vector<double>> ctx(fscales);
+        cwt(ctx, data, psi, x);
+        if (ctx.result != r || ctx.shape != std::vector<size_t>{scales.size(), data.size()}) {
+            std::printf("FAIL ctx overload\n");
+            return 1;
+        }
+        return 0;
+    }
     if (mode == "api") {
         // argument errors of the design functions (reference dsp.hpp:76-78, 200-215)
         CHECK(throws<std::invalid_argument>([] { firwin<double>(100, std::vector<double>{}); }));
@@ -78,6 +105,9 @@ int main(int argc, char** argv) {
         CHECK(firwin<double>(101, 0.5, false).size() == 101);
         CHECK(firwin<float>(33, 0.25f).size() == 33);
         CHECK(std::abs(sinc<double>(0.0) - 1.0) < 1e-15);
+        CHECK(throws<std::invalid_argument>([] { integrate_wavelet<double>(cwt_wavelet_t::MORLET, 2); }));
+        CHECK(throws<std::invalid_argument>([] { integrate_wavelet<double>(cwt_wavelet_t::MORLET, 10, 1.0, 1.0); }));
+        CHECK(integrate_wavelet<double>(cwt_wavelet_t::MORLET, 4).first.size() == 16);
         if (argc > 2 && std::strcmp(argv[2], "nogpu") == 0) {
             std::printf("OK (design only)\n");
             return 0;
@@ -111,6 +141,16 @@ int main(int argc, char** argv) {
         for (double v : z) CHECK(v == 0.0);
         // IIR denominators are outside the GPU path: loud error, no silent CPU fallback
         CHECK(throws<std::invalid_argument>([&] { lfilter<double>(w, std::vector<double>{1.0, -0.5}, x); }));
+        // wavelet bank: error classes of the reference (dsp.hpp:1047-1119, 1153-1155, 1195-1197)
+        auto [psi, grid] = integrate_wavelet<double>(cwt_wavelet_t::MORLET, 10);
+        CHECK(throws<std::runtime_error>([&] { cwt<double>(x, std::vector<double>{0.0625}, psi, grid); }));   // too small
+        CHECK(throws<std::runtime_error>([&] { cwt<double>(x, std::vector<double>{}, psi, grid); }));         // no scales
+        CHECK(throws<std::invalid_argument>([&] { cwt<double>(std::vector<double>{}, std::vector<double>{1.0}, psi, grid); }));
+        CHECK(throws<std::invalid_argument>([&] { cwt<double>(x, std::vector<double>{1.0}, std::vector<double>{1.0, 2.0}, grid); }));
+        auto rows = cwt<double>(x, std::vector<double>{3.0, 1.0}, psi, grid);  // unsorted scales are sorted
+        auto row1 = cwt<double>(x, std::vector<double>{1.0}, psi, grid);
+        CHECK(rows.size() == 2 * x.size());
+        for (size_t i = 0; i < x.size(); ++i) CHECK(rows[i] == row1[i]);
         std::printf("OK\n");
         return 0;
     }
