@@ -35,6 +35,9 @@ WORKLOADS = {
     "long4095": (1, 1 << 26, 4095, 0.1, "single stream 2^26 samples, 4095-tap firwin(4095, 0.1) (BASELINE configs[3])"),
     "small255": (64, 1 << 20, 255, 0.25, "reduced batch 64 x 2^20 samples, 255 taps (development only)"),
 }
+# dsp::cwt bank (BASELINE configs[4]): Morlet table of 2^10 points, integer scales 1..65, 2^22 samples.
+CWT = {"nscales": 65, "n": 1 << 22, "precision": 10,
+       "desc": "dsp::cwt Morlet bank, 65 integer scales over 2^22 samples (BASELINE configs[4])"}
 PEAK_FP64_TFLOPS = 78.6   # MI355X FP64: 256 CU x 64 FMA/clk x 2 x 2.4 GHz (vector; the FP64 MFMA peak is the same)
 PEAK_HBM_GBS = 8000.0     # MI355X HBM3E
 
@@ -44,7 +47,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="batched255", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="batched255", choices=sorted(WORKLOADS) + ["cwt65"])
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--exact", action="store_true", help="DSPX_FIR_EXACT arithmetic (separate mul/add)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -85,6 +88,81 @@ def cpu_baseline(taps: np.ndarray, n: int, nsamples: int, y_gpu) -> dict:
             "gpu_vs_cpu_max_scaled_err": worst}
 
 
+def run_cwt(args, rank, world, dev, dist):
+    """The wavelet-bank workload: every rank transforms its own 2^22-sample signal (weak scaling)."""
+    import torch
+
+    import dsp_amd
+
+    n, nscales = CWT["n"], CWT["nscales"]
+    psi, wx = dsp_amd.integrate_wavelet(CWT["precision"])
+    scales = np.arange(1, nscales + 1, dtype=np.float64)
+    bank = dsp_amd.CwtBank(scales, psi, wx)
+    sig = torch.empty(n, dtype=torch.float64, device=dev)
+    out = torch.empty((nscales, n), dtype=torch.float64, device=dev)
+    dsp_amd.fill_splitmix(sig, dsp_amd.SEED, rank * n)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        bank.apply(sig, out=out, exact=args.exact)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    fence()
+    t0 = time.perf_counter()
+    ev[0].record()
+    for i in range(args.steps):
+        bank.apply(sig, out=out, exact=args.exact)
+        ev[i + 1].record()
+    fence()
+    dt = time.perf_counter() - t0
+    kern_ms = float(np.mean([ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps)]))
+    t = torch.tensor([dt, kern_ms], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if rank != 0:
+        return
+    dt_max, kern_ms = float(t[0]), float(t[1])
+    flops = 2.0 * bank.total_taps * n            # 2 * 34385 per input sample
+    bytes_alg = (8.0 + 8.0 * nscales) * n        # read once, one output row per scale
+    sec = kern_ms / 1e3
+    res = {
+        "metric": "dsp::cwt input GS/s (65-scale Morlet bank)", "value": world * n * args.steps / dt_max / 1e9,
+        "unit": "GS/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt_max / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic (splitmix64 uniform [-1,1), generated on device, resident in HBM)",
+        "config": {"workload": CWT["desc"], "samples": n, "scales": nscales, "total_taps": bank.total_taps,
+                   "arithmetic": "exact (mul+add)" if args.exact else "fma"},
+        "roofline": {"bound": "mfma", "achieved": flops / sec / 1e12, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
+                     "frac": flops / sec / 1e12 / PEAK_FP64_TFLOPS, "traffic": load_traffic("cwt65"),
+                     "kernel": "fir_f64_kernel (bank mode)", "kernel_ms": kern_ms,
+                     "note": "FP64 FMA; algorithmic flops = 2 * sum of per-scale tap counts per input sample"},
+        "roofline_other": {"bound": "hbm", "achieved": bytes_alg / sec / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                           "frac": bytes_alg / sec / 1e9 / PEAK_HBM_GBS, "traffic": load_traffic("cwt65")},
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        from oracle.pyoracle import SEED, Oracle
+
+        orc = Oracle()
+        m = 1 << 14                               # bounded sample: the first 2^14 samples, all 65 scales
+        xs = orc.fill_splitmix(m, SEED, 0)
+        t0 = time.perf_counter()
+        ref = orc.cwt(xs, scales, psi, wx)
+        cdt = time.perf_counter() - t0
+        # the transform of a prefix differs from the prefix of the transform near its right edge only
+        keep = m - 1100
+        got = out[:, :keep].cpu().numpy()
+        err = max(float(np.max(np.abs(got[r] - ref[r, :keep])) / np.max(np.abs(ref[r, :keep]))) for r in range(nscales))
+        res["cpu_baseline"] = {"value": m / cdt / 1e9, "unit": "GS/s", "cores": 1, "kind": "port",
+                               "sample": f"first {m} samples, all {nscales} scales, {cdt:.1f} s, oracle/cwt_oracle.c "
+                                         "gcc -O2 -ffp-contract=off (bit-identical to the reference loop)",
+                               "gpu_vs_cpu_max_scaled_err": err}
+    print(json.dumps(res), flush=True)
+
+
 def load_traffic(workload: str):
     """HBM bytes per launch from the committed PMC summary, if one exists for this workload."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -116,6 +194,13 @@ def main() -> None:
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend=os.environ.get("DSPX_BENCH_BACKEND", "nccl"), device_id=dev)
+
+    if args.workload == "cwt65":
+        run_cwt(args, rank, world, dev, dist)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     _, n, numtaps, cutoff, desc = WORKLOADS[args.workload]
     nchan, chan0, units_per_step_all = shard(args.workload, rank, world, args.scaling)

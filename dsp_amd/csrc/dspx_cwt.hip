@@ -158,7 +158,8 @@ int apply_bank(const dspx_cwt_bank* bank, const double* d_signal, size_t n, doub
     if (row_stride < n) return fail(DSPX_ERR_INVALID, "row_stride (%zu) < n (%zu)", row_stride, n);
     const size_t stride = (size_t)dspx::fir_bank_stride();
     const size_t tiles_per_row = (n + stride - 1) / stride;
-    const size_t max_rows = 0x7fffffffull / tiles_per_row;
+    const size_t run = (tiles_per_row + 7) / 8;  // tiles per row and XCD
+    const size_t max_rows = 0x7fffffffull / (8 * run);
     if (max_rows == 0) return fail(DSPX_ERR_INVALID, "signal too long for one launch: %zu", n);
     const bool vec2 = dspx::aligned16(d_signal) && dspx::aligned16(d_result) && (row_stride % 2 == 0);
     for (size_t r0 = 0; r0 < bank->nrows; r0 += max_rows) {
@@ -167,8 +168,8 @@ int apply_bank(const dspx_cwt_bank* bank, const double* d_signal, size_t n, doub
         s.y_stride = row_stride;
         s.n = (long long)n;
         s.tiles_per_chan = (unsigned)tiles_per_row;
-        s.total_tiles = (unsigned)(nr * tiles_per_row);
-        dspx::set_tile_divider(s);
+        s.total_tiles = (unsigned)(nr * 8 * run);  // workgroups; those past a row's last tile exit at once
+        dspx::set_divider(s, (unsigned)run);
         DSPX_HIP(dspx::launch_fir_bank_f64(bank->d_taps, bank->d_rows + r0, d_signal, d_result, s,
                                            (flags & DSPX_FIR_EXACT) != 0, vec2, stream));
     }

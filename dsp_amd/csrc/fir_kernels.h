@@ -16,13 +16,14 @@ struct FirShape {
     int ntaps;
 };
 
-// Fills div_magic / div_shift for tiles_per_chan (exact for dividends below 2^31).
-inline void set_tile_divider(FirShape& s) {
+// Fills div_magic / div_shift so that x / d == (x * div_magic) >> div_shift for x < 2^31.
+inline void set_divider(FirShape& s, unsigned d) {
     unsigned l = 0;
-    while ((1ull << l) < s.tiles_per_chan) ++l;
+    while ((1ull << l) < d) ++l;
     s.div_shift = 31 + l;
-    s.div_magic = ((1ull << s.div_shift) + s.tiles_per_chan - 1) / s.tiles_per_chan;
+    s.div_magic = ((1ull << s.div_shift) + d - 1) / d;
 }
+inline void set_tile_divider(FirShape& s) { set_divider(s, s.tiles_per_chan); }
 
 // One row of a filter bank (bank mode of the kernel): its taps, where its results go, the factor
 // applied to the first difference of its convolution, and how far its output is advanced.
@@ -41,7 +42,8 @@ hipError_t launch_fir_f64(const double* taps, const double* x, const double* his
                           bool exact, bool vec2, hipStream_t stream);
 // Bank mode: shape.n = length of the single input and of every output row, shape.y_stride = elements
 // between output rows, shape.tiles_per_chan = ceil(n / fir_bank_stride()), shape.total_tiles =
-// rows * tiles_per_chan; the other strides and ntaps are unused.
+// rows * 8 * ceil(tiles_per_chan / 8) workgroups (each row is cut into 8 runs of tiles, one per XCD; the
+// divider divides by the run length); the other strides and ntaps are unused.
 hipError_t launch_fir_bank_f64(const double* taps, const BankRow* bank, const double* x, double* y,
                                const FirShape& shape, bool exact, bool vec2, hipStream_t stream);
 hipError_t launch_fill_splitmix(double* x, unsigned long long n, unsigned long long seed, unsigned long long offset,

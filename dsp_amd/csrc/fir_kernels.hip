@@ -92,7 +92,8 @@ __device__ __forceinline__ void load_window(const double2* top, int g, double (&
 // BANK = true: one input, a bank of tap vectors of different lengths (the wavelet path, reference
 // dsp.hpp:1136-1217): row r computes c[t] = sum_k taps_r[k] * x[t + advance_r - k] with zeros outside
 // [0, n), and stores (c[i+1] - c[i]) * scale_r for i < n.  A tile still computes 2048 values of c but
-// advances by kBankStride = 2040 outputs, so that the c[i+1] of its last output is its own.
+// advances by kBankStride = 2040 outputs, so that the c[i+1] (or c[i+2], see `odd`) of its last
+// output is its own.
 template <bool EXACT, bool VEC2, bool BANK>
 __global__ __launch_bounds__(kBlock) void fir_f64_kernel(const double* __restrict__ taps,
                                                           const double* __restrict__ x,
@@ -101,18 +102,29 @@ __global__ __launch_bounds__(kBlock) void fir_f64_kernel(const double* __restric
     __shared__ double2 lds[kLdsPairs];
     const int tid = threadIdx.x;
 
-    // Blocks b and b+8 share an XCD (and its L2): give every XCD a contiguous range
-    // of tiles so that neighbouring tiles find their shared halo in the same L2.
+    // Blocks b and b+8 share an XCD (and its L2).  Tiles that are neighbours in time share a halo,
+    // so every XCD gets contiguous runs of tiles and finds the shared samples in its own L2.
     const unsigned b = blockIdx.x;
-    const unsigned q8 = s.total_tiles / 8, r8 = s.total_tiles % 8;
     const unsigned grp = b % 8, k = b / 8;
-    const unsigned tile_id = (grp < r8 ? grp * (q8 + 1) : r8 * (q8 + 1) + (grp - r8) * q8) + k;
-    // tile_id / tiles_per_chan by multiplication (exact for tile_id < 2^31)
-    const unsigned chan = (unsigned)(((unsigned long long)tile_id * s.div_magic) >> s.div_shift);
-    const unsigned tile = tile_id - chan * s.tiles_per_chan;
+    unsigned chan, tile;
+    if constexpr (BANK) {
+        // Rows of a bank differ in cost (tap count), so each row is cut into 8 runs, one per
+        // XCD, and all XCDs work through the rows together (s.div_* divide by the run length).
+        const unsigned run = (s.tiles_per_chan + 7) / 8;
+        chan = (unsigned)(((unsigned long long)k * s.div_magic) >> s.div_shift);
+        tile = grp * run + (k - chan * run);
+        if (tile >= s.tiles_per_chan) return;  // the whole workgroup leaves together
+    } else {
+        // Equal-cost tiles: XCD g takes the g-th eighth of all tiles (s.div_* divide by tiles_per_chan).
+        const unsigned q8 = s.total_tiles / 8, r8 = s.total_tiles % 8;
+        const unsigned tile_id = (grp < r8 ? grp * (q8 + 1) : r8 * (q8 + 1) + (grp - r8) * q8) + k;
+        chan = (unsigned)(((unsigned long long)tile_id * s.div_magic) >> s.div_shift);
+        tile = tile_id - chan * s.tiles_per_chan;
+    }
     const long long n = s.n;
     long long tile_start, pos0;  // first output of the tile; input position its tap 0 multiplies
     int ntaps;
+    int odd = 0;  // bank mode: 1 when the row's advance is odd (the tile then computes c one sample early)
     double post = 1.0;
     const double* __restrict__ xc;
     const double* __restrict__ hc;
@@ -121,7 +133,10 @@ __global__ __launch_bounds__(kBlock) void fir_f64_kernel(const double* __restric
     if constexpr (BANK) {
         const BankRow row = bank[chan];
         tile_start = (long long)tile * kBankStride;
-        pos0 = tile_start + row.advance;
+        // Keep the staged window 16-byte aligned in memory: for an odd advance compute
+        // c'[i] = c[i + advance - 1] instead and shift the difference by one in the epilogue.
+        odd = row.advance & 1;
+        pos0 = tile_start + row.advance - odd;
         ntaps = row.ntaps;
         post = row.scale;
         xc = x, hc = nullptr;
@@ -229,7 +244,8 @@ __global__ __launch_bounds__(kBlock) void fir_f64_kernel(const double* __restric
             const double2 c23 = lds[pn + (pn >> 2)];  // pair_of(2 * pn)
             // first difference times the row's factor, as two separately rounded operations
             // (reference dsp.hpp:1186-1191)
-            const double2 o = make_double2((c01.y - c01.x) * post, (c23.x - c01.y) * post);
+            const double2 o = odd ? make_double2((c23.x - c01.y) * post, (c23.y - c23.x) * post)
+                                  : make_double2((c01.y - c01.x) * post, (c23.x - c01.y) * post);
             if (2 * pi < kBankStride) {
                 if (2 * pi + 1 < left) {
                     if constexpr (VEC2)
@@ -322,7 +338,7 @@ hipError_t launch_fir_f64(const double* taps, const double* x, const double* his
 hipError_t launch_fir_bank_f64(const double* taps, const BankRow* bank, const double* x, double* y,
                                const FirShape& shape, bool exact, bool vec2, hipStream_t stream) {
     if (shape.total_tiles == 0) return hipSuccess;
-    const dim3 grid(shape.total_tiles), block(kBlock);
+    const dim3 grid(shape.total_tiles), block(kBlock);  // rows * 8 * ceil(tiles_per_chan / 8)
     const double* none = nullptr;
     if (exact) {
         if (vec2)

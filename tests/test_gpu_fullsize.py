@@ -141,3 +141,43 @@ def test_unit_dc_gain_everywhere(env):
     assert bool((steady == v).all())
     # warm-up samples are the running sums of the taps in ascending order (FMA with 1.0 is exact)
     assert np.array_equal(bits(y[3, :254].cpu().numpy()), bits(np.cumsum(taps_h)[:254]))
+
+
+def test_cwt_bank_65_scales_2e22(env, oracle, golden):
+    """BASELINE config 5 at full size: windows of several rows against the oracle run on a
+    sub-signal (interior coefficients of a sub-signal's transform equal those of the whole
+    signal's: the same products are added in the same order), and row-sharding invariance."""
+    torch, dsp = env
+    psi, wx = golden["morlet10_psi"], golden["morlet10_x"]
+    n = 1 << 22
+    scales = np.arange(1, 66, dtype=np.float64)
+    bank = dsp.CwtBank(scales, psi, wx)
+    sig = torch.empty(n, dtype=torch.float64, device="cuda")
+    dsp.fill_splitmix(sig, dsp.SEED, 0)
+    out = bank.apply(sig)
+    assert bool(torch.isfinite(out).all())
+    margin, win = 1100, 3000          # margin > the longest kernel (1041 taps)
+    for a in (0, 2040 * 7 - 1500, n // 2 + 777, n - win - 2 * margin):
+        xs = oracle.fill_splitmix(win + 2 * margin, dsp.SEED, a)
+        for s in (1, 2, 16, 33, 65):
+            ref = oracle.cwt(xs, [float(s)], psi, wx)[0]
+            lo = 0 if a == 0 else margin          # the left edge of the signal is a real edge
+            got = out[s - 1, a + lo: a + margin + win].cpu().numpy()
+            assert scaled_err(got, ref[lo: margin + win]) <= TOL, (a, s)
+    # the right edge of the signal
+    xs = oracle.fill_splitmix(win + margin, dsp.SEED, n - win - margin)
+    for s in (1, 65):
+        ref = oracle.cwt(xs, [float(s)], psi, wx)[0]
+        assert scaled_err(out[s - 1, n - win:].cpu().numpy(), ref[margin:]) <= TOL
+    whole = dsp.checksum(out, 0)
+    # scale sharding as 8 GPUs would do it: each device's rows in a bank of their own
+    dev, _ = dsp.cwt_plan(scales, 1024, wx, 8)
+    out2 = torch.zeros_like(out)
+    for g in range(8):
+        rows = [r for r in range(65) if dev[r] == g]
+        sub = dsp.CwtBank(scales[rows], psi, wx)
+        part = sub.apply(sig)
+        out2[rows] = part
+        sub.close()
+    assert dsp.checksum(out2, 0) == whole
+    bank.close()
