@@ -51,7 +51,7 @@ def parse_args():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--exact", action="store_true", help="DSPX_FIR_EXACT arithmetic (separate mul/add)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-samples", type=int, default=1 << 26, help="samples of the workload the CPU baseline filters")
+    ap.add_argument("--cpu-samples", type=int, default=1 << 27, help="samples of the workload the CPU baseline filters")
     return ap.parse_args()
 
 

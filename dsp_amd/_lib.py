@@ -34,6 +34,8 @@ SIGNATURES = {
                                        C.c_size_t, C.c_uint]),
     "dspx_fir_f64_multi": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t,
                                      C.c_size_t, C.c_int, C.c_uint]),
+    "dspx_fir_f64_stream": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                      C.c_size_t, C.c_size_t, C.c_uint]),
     "dspx_fir_plan": (C.c_long, [C.c_size_t, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t]),
     "dspx_fir_f64_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
                                    C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_uint, C.c_void_p]),

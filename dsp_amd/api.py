@@ -50,6 +50,18 @@ def lfilter(b, x, exact: bool = False) -> np.ndarray:
     return y
 
 
+def lfilter_stream(b, hist, x, exact: bool = False) -> np.ndarray:
+    """One chunk of a stream: `hist` (ntaps-1 samples per channel, updated in place) carries the state."""
+    b, x = _np_f64(b), _np_f64(x)
+    assert isinstance(hist, np.ndarray) and hist.dtype == np.float64 and hist.flags.c_contiguous
+    x2 = x.reshape(1, -1) if x.ndim == 1 else x
+    assert hist.size == x2.shape[0] * max(b.size - 1, 0)
+    y = np.empty_like(x2)
+    check(lib().dspx_fir_f64_stream(b.ctypes.data, b.size, hist.ctypes.data, x2.ctypes.data, y.ctypes.data,
+                                    x2.shape[0], x2.shape[1], x2.shape[1], _flags(exact)))
+    return y.reshape(x.shape)
+
+
 def lfilter_multi(b, x, ngpus: int = 0, exact: bool = False) -> np.ndarray:
     b, x = _np_f64(b), _np_f64(x)
     x2 = x.reshape(1, -1) if x.ndim == 1 else x

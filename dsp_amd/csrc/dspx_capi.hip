@@ -124,8 +124,10 @@ struct Slot {
     hipStream_t stream = nullptr;
 };
 
-int run_device(int device, const double* taps, size_t ntaps, const double* x, double* y, size_t stride,
-               const std::vector<Piece>& pieces, unsigned flags) {
+// `hist0`, when non-null, holds for every channel the ntaps-1 samples that precede x[0]
+// (channel c at hist0 + c*(ntaps-1)); null means zeros.
+int run_device(int device, const double* taps, size_t ntaps, const double* hist0, const double* x, double* y,
+               size_t stride, const std::vector<Piece>& pieces, unsigned flags) {
     if (pieces.empty()) return DSPX_OK;
     DSPX_HIP(hipSetDevice(device));
     const size_t hl = ntaps ? ntaps - 1 : 0;
@@ -158,16 +160,25 @@ int run_device(int device, const double* taps, size_t ntaps, const double* x, do
                 DSPX_HIP(hipMalloc(&s.d_out, out_pitch * p.cnt * sizeof(double)));
                 s.out_cap = out_pitch * p.cnt;
             }
-            // history: the lead samples that exist in the caller's buffer, zeros before them
+            // history: the lead samples that exist in the caller's buffer; before them the caller's
+            // initial history (samples s0 .. hl-1 of it when lead == s0 < hl), or zeros
             const size_t lead = std::min(hl, p.s0);
             const double* d_hist = nullptr;
-            if (p.s0 > 0 && hl > 0) {
-                if (lead < hl)
-                    DSPX_HIP(hipMemset2DAsync(s.d_in + (hl_pad - hl), in_pitch * sizeof(double), 0,
-                                              (hl - lead) * sizeof(double), p.cnt, s.stream));
-                DSPX_HIP(hipMemcpy2DAsync(s.d_in + (hl_pad - lead), in_pitch * sizeof(double),
-                                          x + p.c * stride + (p.s0 - lead), stride * sizeof(double),
-                                          lead * sizeof(double), p.cnt, hipMemcpyHostToDevice, s.stream));
+            if ((p.s0 > 0 || hist0) && hl > 0) {
+                if (lead < hl) {
+                    if (hist0)
+                        DSPX_HIP(hipMemcpy2DAsync(s.d_in + (hl_pad - hl), in_pitch * sizeof(double),
+                                                  hist0 + p.c * hl + p.s0, hl * sizeof(double),
+                                                  (hl - lead) * sizeof(double), p.cnt, hipMemcpyHostToDevice,
+                                                  s.stream));
+                    else
+                        DSPX_HIP(hipMemset2DAsync(s.d_in + (hl_pad - hl), in_pitch * sizeof(double), 0,
+                                                  (hl - lead) * sizeof(double), p.cnt, s.stream));
+                }
+                if (lead)
+                    DSPX_HIP(hipMemcpy2DAsync(s.d_in + (hl_pad - lead), in_pitch * sizeof(double),
+                                              x + p.c * stride + (p.s0 - lead), stride * sizeof(double),
+                                              lead * sizeof(double), p.cnt, hipMemcpyHostToDevice, s.stream));
                 d_hist = s.d_in + (hl_pad - hl);
             }
             DSPX_HIP(hipMemcpy2DAsync(s.d_in + hl_pad, in_pitch * sizeof(double), x + p.c * stride + p.s0,
@@ -195,8 +206,8 @@ int run_device(int device, const double* taps, size_t ntaps, const double* x, do
     return rc;
 }
 
-int host_path(const double* taps, size_t ntaps, const double* x, double* y, size_t nchan, size_t n, size_t stride,
-              int ngpus, unsigned flags) {
+int host_path(const double* taps, size_t ntaps, const double* hist0, const double* x, double* y, size_t nchan,
+              size_t n, size_t stride, int ngpus, unsigned flags) {
     if (int rc = check_common(taps, ntaps, x, y, nchan, n, flags)) return rc;
     if (nchan == 0 || n == 0) return DSPX_OK;
     if (stride < n) return fail(DSPX_ERR_INVALID, "stride (%zu) < n (%zu)", stride, n);
@@ -209,7 +220,7 @@ int host_path(const double* taps, size_t ntaps, const double* x, double* y, size
     if (ngpus < 0) {  // single-device entry points: stay on the caller's current device
         std::vector<Piece> pieces;
         cut_pieces(0, nchan, 0, n, pieces);
-        return run_device(cur, taps, ntaps, x, y, stride, pieces, flags);
+        return run_device(cur, taps, ntaps, hist0, x, y, stride, pieces, flags);
     }
     const int G = ngpus == 0 ? ndev : ngpus;
     if (G > ndev) return fail(DSPX_ERR_INVALID, "ngpus (%d) exceeds visible devices (%d)", G, ndev);
@@ -219,7 +230,7 @@ int host_path(const double* taps, size_t ntaps, const double* x, double* y, size
     std::vector<std::thread> workers;
     for (int g = 0; g < G; ++g)
         workers.emplace_back([&, g] {
-            rcs[g] = run_device(g, taps, ntaps, x, y, stride, plan[g], flags);
+            rcs[g] = run_device(g, taps, ntaps, hist0, x, y, stride, plan[g], flags);
             if (rcs[g] != DSPX_OK) msgs[g] = g_last_error;
         });
     for (auto& w : workers) w.join();
@@ -284,18 +295,37 @@ int dspx_hamming_window_f64(size_t width, double alpha, int sym, double* out) {
 double dspx_sinc_f64(double x) { return dsp::sinc<double>(x); }
 
 int dspx_fir_f64(const double* taps, size_t ntaps, const double* x, double* y, size_t n, unsigned flags) {
-    return host_path(taps, ntaps, x, y, 1, n, n, -1, flags);
+    return host_path(taps, ntaps, nullptr, x, y, 1, n, n, -1, flags);
 }
 
 int dspx_fir_f64_batched(const double* taps, size_t ntaps, const double* x, double* y, size_t nchan, size_t n,
                          size_t stride, unsigned flags) {
-    return host_path(taps, ntaps, x, y, nchan, n, stride, -1, flags);
+    return host_path(taps, ntaps, nullptr, x, y, nchan, n, stride, -1, flags);
 }
 
 int dspx_fir_f64_multi(const double* taps, size_t ntaps, const double* x, double* y, size_t nchan, size_t n,
                        size_t stride, int ngpus, unsigned flags) {
     if (ngpus < 0) return fail(DSPX_ERR_INVALID, "ngpus must be >= 0");
-    return host_path(taps, ntaps, x, y, nchan, n, stride, ngpus, flags);
+    return host_path(taps, ntaps, nullptr, x, y, nchan, n, stride, ngpus, flags);
+}
+
+int dspx_fir_f64_stream(const double* taps, size_t ntaps, double* hist, const double* x, double* y, size_t nchan,
+                        size_t n, size_t stride, unsigned flags) {
+    const size_t hl = ntaps ? ntaps - 1 : 0;
+    if (hl && nchan && !hist) return fail(DSPX_ERR_INVALID, "hist is NULL");
+    if (int rc = host_path(taps, ntaps, hl ? hist : nullptr, x, y, nchan, n, stride, -1, flags)) return rc;
+    // the next chunk's history: the last ntaps-1 samples of [hist | x]
+    for (size_t c = 0; c < nchan && hl && n; ++c) {
+        double* h = hist + c * hl;
+        const double* xc = x + c * stride;
+        if (n >= hl) {
+            std::copy(xc + (n - hl), xc + n, h);
+        } else {
+            std::copy(h + n, h + hl, h);
+            std::copy(xc, xc + n, h + (hl - n));
+        }
+    }
+    return DSPX_OK;
 }
 
 long dspx_fir_plan(size_t nchan, size_t n, int ngpus, dspx_piece* out, size_t cap) {

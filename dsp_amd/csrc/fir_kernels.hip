@@ -29,7 +29,10 @@ namespace dspx {
 
 namespace {
 
-constexpr int kBlock = 256;               // threads per workgroup
+#ifndef DSPX_BLOCK
+#define DSPX_BLOCK 256
+#endif
+constexpr int kBlock = DSPX_BLOCK;        // threads per workgroup
 constexpr int kR = 8;                     // outputs per thread
 constexpr int kGroup = 16;                // taps per unrolled group
 constexpr int kWin = kGroup + kR;         // samples a group reads per thread (23 needed, 24 loaded)

@@ -247,6 +247,36 @@ std::vector<T> lfilter(const Container_1& numerators, T denominator, const Conta
     return lfilter<T>(numerators, std::array<T, 1>{denominator}, x);
 }
 
+// ---- addition (no counterpart in the reference): chunked filtering of one long stream ----
+// The reference's lfilter starts every call from a zero state (dsp.hpp:356-365), so a stream
+// cut into chunks cannot be filtered chunk by chunk with it.  lfilter_stream_t carries the
+// last ntaps-1 input samples from one call to the next; the concatenated results equal one
+// lfilter call over the concatenated input, bit for bit.
+template <typename T = double> struct lfilter_stream_t {
+    std::vector<T> history;  // ntaps-1 samples; (re)initialised to zeros when its size does not fit
+    std::vector<T> result;
+};
+
+template <typename T = double, typename Container_1, typename Container_2>
+    requires std::floating_point<T> && indexable_of<Container_1, T> && indexable_of<Container_2, T>
+void lfilter(lfilter_stream_t<T>& stream, const Container_1& numerators, const Container_2& x) {
+    static_assert(std::is_same_v<T, double> && std::is_same_v<typename Container_1::value_type, double> &&
+                    std::is_same_v<typename Container_2::value_type, double>,
+                  "dsp::lfilter (MI355X): only T = double over containers of double is implemented");
+    const std::size_t n = x.size();
+    const std::size_t keep = numerators.size() ? numerators.size() - 1 : 0;
+    if (stream.history.size() != keep) stream.history.assign(keep, 0.0);
+    if (stream.result.size() != n) stream.result.resize(n);
+    if (n == 0) return;
+    const detail::double_view<Container_1> b(numerators);
+    const detail::double_view<Container_2> in(x);
+    const int rc = dspx_fir_f64_stream(b.data(), b.size(), stream.history.data(), in.data(), stream.result.data(), 1,
+                                       n, n, DSPX_FIR_FMA);
+    if (rc != DSPX_OK)
+        throw std::runtime_error(std::string("dsp::lfilter (MI355X): ") + dspx_status_string(rc) + ": " +
+                                 dspx_last_error());
+}
+
 namespace types {
 
 enum class cwt_wavelet_t {

@@ -83,6 +83,14 @@ DSPX_API int dspx_fir_f64_batched(const double* taps, size_t ntaps, const double
 DSPX_API int dspx_fir_f64_multi(const double* taps, size_t ntaps, const double* x, double* y, size_t nchan, size_t n,
                        size_t stride, int ngpus, unsigned flags);
 
+/* Streaming form (no counterpart in the reference, whose lfilter keeps no state between calls,
+ * dsp.hpp:356-365): `hist` (nchan x (ntaps-1) doubles, channel c at hist + c*(ntaps-1)) holds the
+ * samples that precede x; on return it holds the last ntaps-1 samples of [hist | x], ready for the
+ * next chunk.  Zero-filled history makes the first chunk identical to dspx_fir_f64_batched, and
+ * chunked calls reproduce one long call bit for bit. */
+DSPX_API int dspx_fir_f64_stream(const double* taps, size_t ntaps, double* hist, const double* x, double* y,
+                                 size_t nchan, size_t n, size_t stride, unsigned flags);
+
 /* The sharding plan dspx_fir_f64_multi executes, exposed so that it can be inspected and
  * tested without GPUs: piece i covers channels [chan, chan + nchan) x samples
  * [start, start + len) and is assigned to `device`; the pieces of one device are staged

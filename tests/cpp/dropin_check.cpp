@@ -139,6 +139,18 @@ int main(int argc, char** argv) {
         auto z = lfilter<double>(std::vector<double>{}, 1.0, x);
         CHECK(z.size() == x.size());
         for (double v : z) CHECK(v == 0.0);
+        // streaming addition: chunks of a stream reproduce the one-shot result bit for bit
+        {
+            lfilter_stream_t<double> st;
+            std::vector<double> joined;
+            const size_t cuts[] = {0, 1, 30, 63, 64, 2500, 2501, x.size()};
+            for (size_t c = 0; c + 1 < sizeof(cuts) / sizeof(cuts[0]); ++c) {
+                std::vector<double> chunk(x.begin() + cuts[c], x.begin() + cuts[c + 1]);
+                lfilter(st, w, chunk);
+                joined.insert(joined.end(), st.result.begin(), st.result.end());
+            }
+            CHECK(joined == a);
+        }
         // IIR denominators are outside the GPU path: loud error, no silent CPU fallback
         CHECK(throws<std::invalid_argument>([&] { lfilter<double>(w, std::vector<double>{1.0, -0.5}, x); }));
         // wavelet bank: error classes of the reference (dsp.hpp:1047-1119, 1153-1155, 1195-1197)

@@ -203,3 +203,21 @@ def test_nan_inf_samples_stay_local(dsp, oracle):
     for exact in (True, False):
         y = dsp.lfilter(b, x, exact=exact)
         assert np.array_equal(np.isfinite(y), np.isfinite(ref))
+
+
+@pytest.mark.parametrize("ntaps", [1, 2, 33, 255])
+def test_streaming_chunks_reproduce_one_call(dsp, oracle, ntaps):
+    """dspx_fir_f64_stream: history carried between chunks (also chunks shorter than the filter)."""
+    rng = np.random.default_rng(ntaps)
+    b = rng.standard_normal(ntaps)
+    nchan, n = 3, 7000
+    x = np.stack([oracle.fill_splitmix(n, dsp.SEED, c * n) for c in range(nchan)])
+    ref = np.stack([oracle.lfilter(b, [1.0], x[c]) for c in range(nchan)])
+    hist = np.zeros((nchan, max(ntaps - 1, 0)))
+    out = []
+    cuts = [0, 1, 2, 10, 11, 300, 2348, 2349, 6999, n]
+    for a, e in zip(cuts[:-1], cuts[1:]):
+        out.append(dsp.lfilter_stream(b, hist, np.ascontiguousarray(x[:, a:e]), exact=True))
+    assert np.array_equal(bits(np.concatenate(out, axis=1)), bits(ref))
+    if ntaps > 1:
+        assert np.array_equal(bits(hist), bits(x[:, n - (ntaps - 1):]))
