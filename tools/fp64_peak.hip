@@ -109,6 +109,54 @@ __global__ __launch_bounds__(256) void mfma_loop(double* out, int iters, double 
     }
 }
 
+// Both pipes at once: every wave interleaves independent v_fma_f64 chains (VF of them per MFMA)
+// with v_mfma_f64_16x16x4_f64 chains, all on per-lane random operands.
+template <int MACC, int VF>
+__global__ __launch_bounds__(256) void mixed_loop(double* out, int iters, double a, double b, unsigned long long* clk) {
+    d4 macc[MACC];
+    double vacc[8], xm[8], ya[8], av4[4], bv4[4];
+    unsigned long long z = 0x9E3779B97F4A7C15ull * (blockIdx.x * 256 + threadIdx.x + 1);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;
+        xm[i] = (double)(z >> 11) * 0x1.0p-53 * a;
+        z += 0x9E3779B97F4A7C15ull;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;
+        ya[i] = (double)(z >> 11) * 0x1.0p-53 - 0.5 + b;
+        vacc[i] = ya[i];
+        if (i < 4) av4[i] = xm[i] - 0.3, bv4[i] = ya[i];
+    }
+#pragma unroll
+    for (int i = 0; i < MACC; ++i) macc[i] = d4{0.0, 0.0, 0.0, 0.0};
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int i = 0; i < MACC; ++i) {
+                macc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(av4[(u + i) & 3], bv4[u], macc[i], 0, 0, 0);
+#pragma unroll
+                for (int v = 0; v < VF; ++v) {
+                    const int q = (i * VF + v + u) & 7;
+                    vacc[q] = __builtin_fma(vacc[q], xm[(q + u) & 7], ya[(q + 3 * u) & 7]);
+                }
+            }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+    double s = 0;
+#pragma unroll
+    for (int i = 0; i < MACC; ++i) s += macc[i][0] + macc[i][1] + macc[i][2] + macc[i][3];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += vacc[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    if (threadIdx.x == 0) {
+        clk[2 * blockIdx.x] = t1 - t0;
+        clk[2 * blockIdx.x + 1] = r1 - r0;
+    }
+}
+
 template <typename K> void run(const char* name, K kernel, double flops_per_thread_iter, int blocks_per_cu, int iters, double seconds) {
     const int blocks = 256 * blocks_per_cu;
     double* out;
@@ -154,5 +202,11 @@ int main() {
     run("mfma acc4", mfma_loop<4>, 32.0 * 4 * 4, 2, 10000, 2.0);
     run("mfma acc8", mfma_loop<8>, 32.0 * 8 * 4, 1, 5000, 2.0);
     run("mfma acc2", mfma_loop<2>, 32.0 * 2 * 4, 4, 10000, 2.0);
+    // mixed: per MFMA (32 flops/lane) VF vector FMAs (2 flops/lane each)
+    run("mix 4:4", mixed_loop<4, 4>, (32.0 + 2.0 * 4) * 4 * 4, 2, 5000, 2.0);
+    run("mix 4:8", mixed_loop<4, 8>, (32.0 + 2.0 * 8) * 4 * 4, 2, 5000, 2.0);
+    run("mix 4:12", mixed_loop<4, 12>, (32.0 + 2.0 * 12) * 4 * 4, 2, 5000, 2.0);
+    run("mix 4:16", mixed_loop<4, 16>, (32.0 + 2.0 * 16) * 4 * 4, 2, 5000, 2.0);
+    run("mix 4:16", mixed_loop<4, 16>, (32.0 + 2.0 * 16) * 4 * 4, 4, 5000, 2.0);
     return 0;
 }
