@@ -14,6 +14,8 @@ LIB_PATH = os.environ.get("DSPX_LIB") or os.path.join(_HERE, "lib", "libdspx.so"
 DSPX_OK = 0
 DSPX_FIR_FMA = 0
 DSPX_FIR_EXACT = 1
+DSPX_FIR_MFMA = 2
+DSPX_FIR_VECTOR = 4
 
 class Piece(C.Structure):
     _fields_ = [("device", C.c_int), ("chan", C.c_size_t), ("nchan", C.c_size_t), ("start", C.c_size_t),

@@ -11,7 +11,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import DSPX_FIR_EXACT, DSPX_FIR_FMA, check, lib
+from ._lib import DSPX_FIR_EXACT, DSPX_FIR_FMA, DSPX_FIR_MFMA, DSPX_FIR_VECTOR, check, lib
 
 SEED = 0x44535046495236
 
@@ -20,8 +20,14 @@ def device_count() -> int:
     return int(lib().dspx_device_count())
 
 
-def _flags(exact: bool) -> int:
-    return DSPX_FIR_EXACT if exact else DSPX_FIR_FMA
+def _flags(exact: bool, mfma=None) -> int:
+    """exact -> DSPX_FIR_EXACT; mfma: None = library's choice, True / False = force the matrix / vector pipe."""
+    f = DSPX_FIR_EXACT if exact else DSPX_FIR_FMA
+    if mfma is True:
+        f |= DSPX_FIR_MFMA
+    elif mfma is False:
+        f |= DSPX_FIR_VECTOR
+    return f
 
 
 def _np_f64(a) -> np.ndarray:
@@ -36,15 +42,15 @@ def firwin(numtaps: int, cutoff, pass_zero: bool = True, scale: bool = True) -> 
     return out[: int(numtaps)]
 
 
-def lfilter(b, x, exact: bool = False) -> np.ndarray:
+def lfilter(b, x, exact: bool = False, mfma=None) -> np.ndarray:
     """dsp::lfilter(b, 1.0, x) for host arrays: 1-D x, or 2-D (channels, samples)."""
     b, x = _np_f64(b), _np_f64(x)
     y = np.empty_like(x)
     if x.ndim == 1:
-        check(lib().dspx_fir_f64(b.ctypes.data, b.size, x.ctypes.data, y.ctypes.data, x.size, _flags(exact)))
+        check(lib().dspx_fir_f64(b.ctypes.data, b.size, x.ctypes.data, y.ctypes.data, x.size, _flags(exact, mfma)))
     elif x.ndim == 2:
         check(lib().dspx_fir_f64_batched(b.ctypes.data, b.size, x.ctypes.data, y.ctypes.data, x.shape[0], x.shape[1],
-                                         x.shape[1], _flags(exact)))
+                                         x.shape[1], _flags(exact, mfma)))
     else:
         raise ValueError("x must be 1-D or 2-D")
     return y
@@ -79,17 +85,17 @@ def integrate_wavelet(precision: int = 10, lower: float = -8.0, upper: float = 8
     return psi, x
 
 
-def cwt(signal, scales, psi, wx, exact: bool = False, ngpus=None) -> np.ndarray:
+def cwt(signal, scales, psi, wx, exact: bool = False, ngpus=None, mfma=None) -> np.ndarray:
     """dsp::cwt(signal, scales, psi, x) for host arrays -> (len(scales), len(signal)), rows by ascending scale."""
     signal, scales, psi, wx = _np_f64(signal), _np_f64(np.atleast_1d(scales)), _np_f64(psi), _np_f64(wx)
     out = np.empty((scales.size, signal.size), dtype=np.float64)
     if ngpus is None:
         rc = lib().dspx_cwt_f64(signal.ctypes.data, signal.size, scales.ctypes.data, scales.size, psi.ctypes.data,
-                                psi.size, wx.ctypes.data, wx.size, out.ctypes.data, _flags(exact))
+                                psi.size, wx.ctypes.data, wx.size, out.ctypes.data, _flags(exact, mfma))
     else:
         rc = lib().dspx_cwt_f64_multi(signal.ctypes.data, signal.size, scales.ctypes.data, scales.size,
                                       psi.ctypes.data, psi.size, wx.ctypes.data, wx.size, out.ctypes.data, int(ngpus),
-                                      _flags(exact))
+                                      _flags(exact, mfma))
     check(rc)
     return out
 
@@ -116,7 +122,7 @@ class CwtBank:
         self.rows = int(lib().dspx_cwt_bank_rows(h))
         self.total_taps = int(lib().dspx_cwt_bank_total_taps(h))
 
-    def apply(self, signal, out=None, exact: bool = False):
+    def apply(self, signal, out=None, exact: bool = False, mfma=None):
         import torch
 
         assert signal.is_cuda and signal.dtype == torch.float64 and signal.dim() == 1 and signal.is_contiguous()
@@ -124,7 +130,7 @@ class CwtBank:
             out = torch.empty((self.rows, signal.numel()), dtype=torch.float64, device=signal.device)
         assert out.shape == (self.rows, signal.numel()) and out.stride(1) == 1
         check(lib().dspx_cwt_bank_apply_dev(self._h, signal.data_ptr(), signal.numel(), out.data_ptr(), out.stride(0),
-                                            _flags(exact), _stream_ptr()))
+                                            _flags(exact, mfma), _stream_ptr()))
         return out
 
     def close(self):
@@ -157,7 +163,7 @@ def _stream_ptr():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-def fir_device(taps, x, out=None, hist=None, exact: bool = False):
+def fir_device(taps, x, out=None, hist=None, exact: bool = False, mfma=None):
     """Filters a float64 CUDA tensor x of shape (n,) or (channels, n) with device taps.
     `hist`, if given, has shape (..., ntaps-1): the samples preceding x along the last axis."""
     import torch
@@ -176,7 +182,8 @@ def fir_device(taps, x, out=None, hist=None, exact: bool = False):
         assert h2.stride(1) == 1 or h2.shape[1] <= 1
         hptr, hstride = h2.data_ptr(), h2.stride(0)
     check(lib().dspx_fir_f64_dev(taps.data_ptr(), taps.numel(), x2.data_ptr(), x2.stride(0), hptr, hstride,
-                                 o2.data_ptr(), o2.stride(0), x2.shape[0], x2.shape[1], _flags(exact), _stream_ptr()))
+                                 o2.data_ptr(), o2.stride(0), x2.shape[0], x2.shape[1], _flags(exact, mfma),
+                                 _stream_ptr()))
     return out.reshape(x.shape) if out.dim() != x.dim() else out
 
 

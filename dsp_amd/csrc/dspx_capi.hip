@@ -51,7 +51,8 @@ bool ranges_overlap(const void* a, size_t abytes, const void* b, size_t bbytes) 
 int launch_dev(const double* d_taps, size_t ntaps, const double* d_x, size_t x_stride, const double* d_hist,
                size_t hist_stride, double* d_y, size_t y_stride, size_t nchan, size_t n, unsigned flags,
                hipStream_t stream) {
-    const size_t tile = (size_t)dspx::fir_tile();
+    const bool mfma = dspx::use_matrix_pipe(flags, ntaps);
+    const size_t tile = (size_t)(mfma ? dspx::fir_mfma_tile() : dspx::fir_tile());
     const size_t tiles_per_chan = (n + tile - 1) / tile;
     if (tiles_per_chan > 0xffffffffull) return fail(DSPX_ERR_INVALID, "n too large for one launch: %zu", n);
     const bool vec2 = aligned16(d_x) && aligned16(d_y) && (x_stride % 2 == 0) && (y_stride % 2 == 0);
@@ -68,15 +69,20 @@ int launch_dev(const double* d_taps, size_t ntaps, const double* d_x, size_t x_s
         s.tiles_per_chan = (unsigned)tiles_per_chan;
         s.ntaps = (int)ntaps;
         dspx::set_tile_divider(s);
-        DSPX_HIP(dspx::launch_fir_f64(d_taps, d_x + c0 * x_stride, d_hist ? d_hist + c0 * hist_stride : nullptr,
-                                      d_y + c0 * y_stride, s, (flags & DSPX_FIR_EXACT) != 0, vec2, stream));
+        if (mfma)
+            DSPX_HIP(dspx::launch_fir_mfma_f64(d_taps, d_x + c0 * x_stride,
+                                               d_hist ? d_hist + c0 * hist_stride : nullptr, d_y + c0 * y_stride, s,
+                                               vec2, stream));
+        else
+            DSPX_HIP(dspx::launch_fir_f64(d_taps, d_x + c0 * x_stride, d_hist ? d_hist + c0 * hist_stride : nullptr,
+                                          d_y + c0 * y_stride, s, (flags & DSPX_FIR_EXACT) != 0, vec2, stream));
     }
     return DSPX_OK;
 }
 
 int check_common(const double* taps, size_t ntaps, const void* x, const void* y, size_t nchan, size_t n,
                  unsigned flags) {
-    if (flags & ~DSPX_FIR_EXACT) return fail(DSPX_ERR_INVALID, "unknown flag bits 0x%x", flags);
+    if (int rc = dspx::check_flags(flags)) return rc;
     if (ntaps > 0x7fffffffull) return fail(DSPX_ERR_INVALID, "ntaps too large: %zu", ntaps);
     if (ntaps && !taps) return fail(DSPX_ERR_INVALID, "taps is NULL");
     if (nchan && n && (!x || !y)) return fail(DSPX_ERR_INVALID, "x or y is NULL");
@@ -113,7 +119,10 @@ std::vector<std::vector<Piece>> make_plan(size_t nchan, size_t n, int G) {
     if (nchan >= (size_t)G) {
         for (int g = 0; g < G; ++g) cut_pieces(nchan * g / G, nchan * (g + 1) / G, 0, n, plan[g]);
     } else {
-        for (int g = 0; g < G; ++g) cut_pieces(0, nchan, n * g / G, n * (g + 1) / G, plan[g]);
+        // segment starts are multiples of 4: the matrix-pipe kernel groups taps in fours by an output's
+        // distance from the start of its call, so such cuts leave every output's arithmetic unchanged
+        auto cut = [&](int g) { return g == G ? n : (n * g / G) & ~size_t(3); };
+        for (int g = 0; g < G; ++g) cut_pieces(0, nchan, cut(g), cut(g + 1), plan[g]);
     }
     return plan;
 }
@@ -313,6 +322,9 @@ int dspx_fir_f64_stream(const double* taps, size_t ntaps, double* hist, const do
                         size_t n, size_t stride, unsigned flags) {
     const size_t hl = ntaps ? ntaps - 1 : 0;
     if (hl && nchan && !hist) return fail(DSPX_ERR_INVALID, "hist is NULL");
+    // chunk lengths are arbitrary, so unless the caller insists the chunks run on the vector pipe,
+    // whose per-output arithmetic does not depend on where a call starts
+    if (!(flags & DSPX_FIR_MFMA)) flags |= DSPX_FIR_VECTOR;
     if (int rc = host_path(taps, ntaps, hl ? hist : nullptr, x, y, nchan, n, stride, -1, flags)) return rc;
     // the next chunk's history: the last ntaps-1 samples of [hist | x]
     for (size_t c = 0; c < nchan && hl && n; ++c) {

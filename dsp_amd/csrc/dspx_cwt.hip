@@ -151,12 +151,15 @@ int make_bank(const Tables& t, const double* psi, const std::vector<size_t>& pic
 
 int apply_bank(const dspx_cwt_bank* bank, const double* d_signal, size_t n, double* d_result, size_t row_stride,
                unsigned flags, hipStream_t stream) {
-    if (flags & ~DSPX_FIR_EXACT) return fail(DSPX_ERR_INVALID, "unknown flag bits 0x%x", flags);
+    if (int rc = dspx::check_flags(flags)) return rc;
     if (!bank) return fail(DSPX_ERR_INVALID, "bank is NULL");
     if (n == 0) return fail(DSPX_ERR_INVALID, "The size of signal must be greater than 0.");
     if (!d_signal || !d_result) return fail(DSPX_ERR_INVALID, "NULL pointer");
     if (row_stride < n) return fail(DSPX_ERR_INVALID, "row_stride (%zu) < n (%zu)", row_stride, n);
-    const size_t stride = (size_t)dspx::fir_bank_stride();
+    // One rule for every bank, whatever rows it holds, so that a row's bits do not depend on which other
+    // rows share its launch (scale sharding over GPUs must not change results).
+    const bool mfma = dspx::use_matrix_pipe(flags, dspx::kMatrixPipeMinTaps);
+    const size_t stride = (size_t)(mfma ? dspx::fir_mfma_bank_stride() : dspx::fir_bank_stride());
     const size_t tiles_per_row = (n + stride - 1) / stride;
     const size_t run = (tiles_per_row + 7) / 8;  // tiles per row and XCD
     const size_t max_rows = 0x7fffffffull / (8 * run);
@@ -170,8 +173,12 @@ int apply_bank(const dspx_cwt_bank* bank, const double* d_signal, size_t n, doub
         s.tiles_per_chan = (unsigned)tiles_per_row;
         s.total_tiles = (unsigned)(nr * 8 * run);  // workgroups; those past a row's last tile exit at once
         dspx::set_divider(s, (unsigned)run);
-        DSPX_HIP(dspx::launch_fir_bank_f64(bank->d_taps, bank->d_rows + r0, d_signal, d_result, s,
-                                           (flags & DSPX_FIR_EXACT) != 0, vec2, stream));
+        if (mfma)
+            DSPX_HIP(dspx::launch_fir_mfma_bank_f64(bank->d_taps, bank->d_rows + r0, d_signal, d_result, s, vec2,
+                                                    stream));
+        else
+            DSPX_HIP(dspx::launch_fir_bank_f64(bank->d_taps, bank->d_rows + r0, d_signal, d_result, s,
+                                               (flags & DSPX_FIR_EXACT) != 0, vec2, stream));
     }
     return DSPX_OK;
 }
@@ -208,7 +215,7 @@ int run_cwt_device(int device, const Tables& t, const double* psi, const std::ve
 
 int cwt_host(const double* signal, size_t n, const double* scales, size_t nscales, const double* psi, size_t npsi,
              const double* wx, size_t nx, double* result, int ngpus, unsigned flags) {
-    if (flags & ~DSPX_FIR_EXACT) return fail(DSPX_ERR_INVALID, "unknown flag bits 0x%x", flags);
+    if (int rc = dspx::check_flags(flags)) return rc;
     if (!psi) return fail(DSPX_ERR_INVALID, "wavelet_psi is NULL");
     Tables t;
     if (int rc = build_tables(scales, nscales, npsi, wx, nx, n, true, t)) return rc;

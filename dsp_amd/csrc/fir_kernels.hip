@@ -282,6 +282,239 @@ __global__ __launch_bounds__(kBlock) void fir_f64_kernel(const double* __restric
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Toeplitz-block variant on the FP64 matrix pipe (v_mfma_f64_16x16x4_f64).
+//
+// One wave computes 16 segments (matrix columns n) of 64 consecutive outputs each, as four
+// 16-row blocks per segment.  For a tap offset d (a multiple of 4) the product
+//     D[m][n] += sum_k A[m][k] * B[k][n],   A[m][k] = taps[d + m - k],   B[k][n] = x[seg(n) + i0 - d + k]
+// adds, to output i0 + m of every segment, the four taps d+m-3 .. d+m.  A is the same 16x4
+// Toeplitz block for every segment and every i0 (one LDS read per step from a zero-padded copy
+// of the stage's taps); B is four consecutive input samples of each segment (one LDS read per
+// product).  A stage of S taps takes floor((S+2)/4) + 4 steps: the band is about S + 16 columns
+// wide instead of S, so 6 % of the multiplies are by zero at 256 taps.
+//
+// Why it exists: on random data the chip holds ~2.39 GHz while issuing these products but only
+// ~1.9 GHz while issuing v_fma_f64 back to back, so the matrix pipe delivers more FP64 work
+// per second even after the zero multiplies (measured: tools/fp64_peak.hip).
+//
+// Differences from the vector kernel: within a step the four taps of an output are added in
+// descending order (steps ascend), so rounding differs slightly (same error bound).  The zero
+// taps at the band edges multiply real samples, and 0 * Inf is NaN; so a workgroup whose
+// staged window holds a non-finite sample computes its tile with a plain per-output FMA loop
+// instead, which adds exactly the products the reference adds.
+constexpr int kMSeg = 64;                      // outputs per segment
+constexpr int kMWaveOut = 16 * kMSeg;          // outputs per wave
+constexpr int kMTile = (kBlock / 64) * kMWaveOut;  // outputs per workgroup (4096)
+constexpr int kMBankStride = kMTile - 2;       // outputs per workgroup in bank mode (two spare values of c)
+constexpr int kMHalo = 256;                    // staged samples in front of the tile (>= taps per stage)
+constexpr int kMStageTaps = 256;
+constexpr int kMSlots = kMHalo + kMTile;
+constexpr int kMPairs = (kMSlots + 2 * (kMSlots / 64)) / 2;   // image: 2 pad doubles per 64 samples
+constexpr int kMTapSlots = kMStageTaps + 40;   // zero-padded stage taps: index j + 15 for j in [-15, S + 18)
+constexpr int kMStageIters = (kMSlots / 2 + kBlock - 1) / kBlock;
+typedef double mfma_d4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ bool not_finite(double v) {
+    return (__double_as_longlong(v) & 0x7ff0000000000000ll) == 0x7ff0000000000000ll;
+}
+
+template <bool VEC2, bool BANK>
+__global__ __launch_bounds__(kBlock) void fir_f64_mfma_kernel(const double* __restrict__ taps,
+                                                               const double* __restrict__ x,
+                                                               const double* __restrict__ hist,
+                                                               double* __restrict__ y,
+                                                               const BankRow* __restrict__ bank, FirShape s) {
+    __shared__ double2 img[kMPairs];
+    __shared__ double tapz[kMTapSlots];
+    __shared__ int bad_flag;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+
+    // tile assignment: as in fir_f64_kernel
+    const unsigned b = blockIdx.x;
+    const unsigned grp = b % 8, k8 = b / 8;
+    unsigned chan, tile;
+    if constexpr (BANK) {
+        const unsigned run = (s.tiles_per_chan + 7) / 8;
+        chan = (unsigned)(((unsigned long long)k8 * s.div_magic) >> s.div_shift);
+        tile = grp * run + (k8 - chan * run);
+        if (tile >= s.tiles_per_chan) return;
+    } else {
+        const unsigned q8 = s.total_tiles / 8, r8 = s.total_tiles % 8;
+        const unsigned tile_id = (grp < r8 ? grp * (q8 + 1) : r8 * (q8 + 1) + (grp - r8) * q8) + k8;
+        chan = (unsigned)(((unsigned long long)tile_id * s.div_magic) >> s.div_shift);
+        tile = tile_id - chan * s.tiles_per_chan;
+    }
+    const long long n = s.n;
+    long long tile_start, pos0;
+    int ntaps, odd = 0;
+    double post = 1.0;
+    const double* __restrict__ xc;
+    const double* __restrict__ hc;
+    const double* __restrict__ tapsc;
+    double* __restrict__ yrow;
+    if constexpr (BANK) {
+        const BankRow row = bank[chan];
+        tile_start = (long long)tile * kMBankStride;
+        odd = row.advance & 1;
+        pos0 = tile_start + row.advance - odd;
+        ntaps = row.ntaps;
+        post = row.scale;
+        xc = x, hc = nullptr;
+        tapsc = taps + row.taps_off;
+        yrow = y + row.out_off * s.y_stride;
+    } else {
+        tile_start = (long long)tile * kMTile;
+        pos0 = tile_start;
+        ntaps = s.ntaps;
+        xc = x + (unsigned long long)chan * s.x_stride;
+        hc = hist ? hist + (unsigned long long)chan * s.hist_stride : nullptr;
+        tapsc = taps;
+        yrow = y + (unsigned long long)chan * s.y_stride;
+    }
+
+    mfma_d4 acc[4];
+#pragma unroll
+    for (int ob = 0; ob < 4; ++ob) acc[ob] = mfma_d4{0.0, 0.0, 0.0, 0.0};
+    if (tid == 0) bad_flag = 0;
+
+    const double* imgd = reinterpret_cast<const double*>(img);
+    // lane (k = lane >> 4, n = lane & 15): image address of sample seg(n) + k, and tap slot of m - k at d = -12
+    const int b_base = (kMHalo + wave * kMWaveOut) / 64 * 66 + 66 * (lane & 15) + (lane >> 4);
+    const int a_base = 3 + (lane & 15) - (lane >> 4);
+    bool bad = false;
+
+    for (int j0 = 0; j0 < ntaps; j0 += kMStageTaps) {
+        const int S = min(kMStageTaps, ntaps - j0);
+        const int steps = (S + 2) / 4 + 4;
+        __syncthreads();  // previous stage fully consumed (and bad_flag initialised)
+        // taps j0 .. j0+S-1 at tapz[15 ..], zeros around them
+        for (int i = tid; i < kMTapSlots; i += kBlock) {
+            const int j = i - 15;
+            tapz[i] = (j >= 0 && j < S) ? tapsc[j0 + j] : 0.0;
+        }
+        // samples: slot q <- sample pos0 - j0 - kMHalo + q, from the lowest pad group the products read
+        const int qlo = (kMHalo - (4 * steps - 16)) & ~63;
+        const int npairs = (kMSlots - qlo) / 2;
+        const long long g_lo = pos0 - j0 - kMHalo + qlo;
+        double2* stage = img + (qlo >> 1) + (qlo >> 6);
+        bool mine_bad = false;
+        if (g_lo >= 0 && g_lo + (kMSlots - qlo) <= n) {  // interior tile: no edge tests
+            const double* __restrict__ src = xc + g_lo;
+#pragma unroll
+            for (int i = 0; i < kMStageIters; ++i) {
+                const int pi = tid + i * kBlock;
+                if (i < kMStageIters - 1 || pi < npairs) {
+                    double2 v;
+                    if constexpr (VEC2)
+                        v = reinterpret_cast<const double2*>(src)[pi];
+                    else
+                        v = make_double2(src[2 * pi], src[2 * pi + 1]);
+                    mine_bad = mine_bad || not_finite(v.x) || not_finite(v.y);
+                    stage[pi + (pi >> 5)] = v;
+                }
+            }
+        } else {
+#pragma unroll 1
+            for (int pi = tid; pi < npairs; pi += kBlock) {
+                const double2 v = make_double2(sample_at(xc, hc, g_lo + 2 * pi, n, ntaps),
+                                               sample_at(xc, hc, g_lo + 2 * pi + 1, n, ntaps));
+                mine_bad = mine_bad || not_finite(v.x) || not_finite(v.y);
+                stage[pi + (pi >> 5)] = v;
+            }
+        }
+        if (mine_bad) bad_flag = 1;
+        __syncthreads();
+        bad = bad_flag != 0;  // workgroup-uniform
+        if (bad) break;
+
+        double a_cur = tapz[a_base];
+        double b_cur[4];
+#pragma unroll
+        for (int ob = 0; ob < 4; ++ob) {
+            const int off = 16 * ob + 12;
+            b_cur[ob] = imgd[b_base + off + 2 * (off >> 6)];
+        }
+        for (int e = 0; e < steps; ++e) {
+            const int en = min(e + 1, steps - 1);  // operands of the next step, fetched under this step's products
+            const double a_nxt = tapz[a_base + 4 * en];
+            double b_nxt[4];
+#pragma unroll
+            for (int ob = 0; ob < 4; ++ob) {
+                const int off = 16 * ob + 12 - 4 * en;  // i0 - d, a multiple of 4, may be negative
+                b_nxt[ob] = imgd[b_base + off + 2 * (off >> 6)];
+            }
+#pragma unroll
+            for (int ob = 0; ob < 4; ++ob)
+                acc[ob] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_cur, b_cur[ob], acc[ob], 0, 0, 0);
+            a_cur = a_nxt;
+#pragma unroll
+            for (int ob = 0; ob < 4; ++ob) b_cur[ob] = b_nxt[ob];
+        }
+    }
+
+    double* __restrict__ yt = yrow + tile_start;
+    const long long left = n - tile_start;
+    constexpr int kOutputs = BANK ? kMBankStride : kMTile;
+
+    if (bad) {
+        // A non-finite sample is in reach of this tile: add exactly the products the reference adds,
+        // one output at a time (every sample comes from memory again; rare and slow by design).
+        const int extra = BANK ? 1 + odd : 0;  // bank mode needs c one or two samples past the tile
+        __syncthreads();
+        double* cbuf = reinterpret_cast<double*>(img);
+        for (int o = tid; o < kOutputs + extra + 1; o += kBlock) {
+            double sum = 0.0;
+            for (int j = 0; j < ntaps; ++j) {
+                const long long g = pos0 + o - j;
+                if (g >= 0 && g < n)
+                    sum = __builtin_fma(tapsc[j], xc[g], sum);
+                else if (g < 0 && hc != nullptr && g >= -(long long)(ntaps - 1))
+                    sum = __builtin_fma(tapsc[j], hc[(ntaps - 1) + g], sum);
+            }
+            cbuf[o] = sum;
+        }
+        __syncthreads();
+        for (int o = tid; o < kOutputs; o += kBlock) {
+            if (o < left) yt[o] = BANK ? (cbuf[o + odd + 1] - cbuf[o + odd]) * post : cbuf[o];
+        }
+        return;
+    }
+
+    // ---- accumulators -> LDS -> coalesced stores.  acc[ob][r] is output 16*ob + (lane >> 4) + 4r of segment lane & 15 ----
+    __syncthreads();
+    double* outd = reinterpret_cast<double*>(img);
+    const int o_base = wave * (kMWaveOut / 64 * 66) + 66 * (lane & 15) + (lane >> 4);
+#pragma unroll
+    for (int ob = 0; ob < 4; ++ob) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) outd[o_base + 16 * ob + 4 * r] = acc[ob][r];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < kMTile / 2 / kBlock; ++i) {
+        const int pi = tid + i * kBlock;
+        double2 o = img[pi + (pi >> 5)];
+        if constexpr (BANK) {
+            // (c[i+1] - c[i]) * factor, shifted by one when the advance was rounded down
+            const int pn = min(pi + 1, kMTile / 2 - 1);
+            const double2 c23 = img[pn + (pn >> 5)];
+            o = odd ? make_double2((c23.x - o.y) * post, (c23.y - c23.x) * post)
+                    : make_double2((o.y - o.x) * post, (c23.x - o.y) * post);
+            if (2 * pi >= kMBankStride) continue;
+        }
+        if (2 * pi + 1 < left) {
+            if constexpr (VEC2)
+                reinterpret_cast<double2*>(yt)[pi] = o;
+            else
+                yt[2 * pi] = o.x, yt[2 * pi + 1] = o.y;
+        } else if (2 * pi < left) {
+            yt[2 * pi] = o.x;
+        }
+    }
+}
+
 // SplitMix64 finaliser.
 __device__ __forceinline__ unsigned long long mix64(unsigned long long z) {
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
@@ -317,6 +550,33 @@ __global__ __launch_bounds__(256) void checksum_kernel(const double* __restrict_
 }  // namespace
 
 int fir_tile() { return kTile; }
+int fir_mfma_tile() { return kMTile; }
+int fir_mfma_bank_stride() { return kMBankStride; }
+
+hipError_t launch_fir_mfma_f64(const double* taps, const double* x, const double* hist, double* y,
+                               const FirShape& shape, bool vec2, hipStream_t stream) {
+    if (shape.total_tiles == 0) return hipSuccess;
+    const dim3 grid(shape.total_tiles), block(kBlock);
+    const BankRow* none = nullptr;
+    if (vec2)
+        hipLaunchKernelGGL((fir_f64_mfma_kernel<true, false>), grid, block, 0, stream, taps, x, hist, y, none, shape);
+    else
+        hipLaunchKernelGGL((fir_f64_mfma_kernel<false, false>), grid, block, 0, stream, taps, x, hist, y, none, shape);
+    return hipGetLastError();
+}
+
+hipError_t launch_fir_mfma_bank_f64(const double* taps, const BankRow* bank, const double* x, double* y,
+                                    const FirShape& shape, bool vec2, hipStream_t stream) {
+    if (shape.total_tiles == 0) return hipSuccess;
+    const dim3 grid(shape.total_tiles), block(kBlock);
+    const double* none = nullptr;
+    if (vec2)
+        hipLaunchKernelGGL((fir_f64_mfma_kernel<true, true>), grid, block, 0, stream, taps, x, none, y, bank, shape);
+    else
+        hipLaunchKernelGGL((fir_f64_mfma_kernel<false, true>), grid, block, 0, stream, taps, x, none, y, bank, shape);
+    return hipGetLastError();
+}
+
 int fir_bank_stride() { return kBankStride; }
 
 hipError_t launch_fir_f64(const double* taps, const double* x, const double* hist, double* y, const FirShape& shape,

@@ -250,8 +250,9 @@ std::vector<T> lfilter(const Container_1& numerators, T denominator, const Conta
 // ---- addition (no counterpart in the reference): chunked filtering of one long stream ----
 // The reference's lfilter starts every call from a zero state (dsp.hpp:356-365), so a stream
 // cut into chunks cannot be filtered chunk by chunk with it.  lfilter_stream_t carries the
-// last ntaps-1 input samples from one call to the next; the concatenated results equal one
-// lfilter call over the concatenated input, bit for bit.
+// last ntaps-1 input samples from one call to the next.  The chunks run on the vector pipe, so
+// the concatenated results do not depend on where the stream is cut (bit for bit); they agree
+// with one lfilter call over the whole stream to rounding (that call may use the matrix pipe).
 template <typename T = double> struct lfilter_stream_t {
     std::vector<T> history;  // ntaps-1 samples; (re)initialised to zeros when its size does not fit
     std::vector<T> result;

@@ -37,10 +37,14 @@ typedef enum dspx_status {
 } dspx_status;
 
 /* Arithmetic mode of the filter kernels (the `flags` argument). */
-#define DSPX_FIR_FMA 0u   /* default: one fused multiply-add per tap, taps ascending        */
-#define DSPX_FIR_EXACT 1u /* separately rounded multiply then add per tap, taps ascending:
-                             bit-identical to the reference loop compiled without FMA
-                             contraction (dsp.hpp:361-364); half the arithmetic rate        */
+#define DSPX_FIR_FMA 0u    /* default: fused multiply-adds, the library picks the pipe: the FP64 matrix
+                              pipe (Toeplitz-block v_mfma_f64_16x16x4_f64) for filters of 32 taps or more,
+                              the vector pipe (v_fma_f64, taps strictly ascending) below                     */
+#define DSPX_FIR_EXACT 1u  /* separately rounded multiply then add per tap, taps ascending, on the vector
+                              pipe: bit-identical to the reference loop compiled without FMA contraction
+                              (dsp.hpp:361-364); about half the arithmetic rate                              */
+#define DSPX_FIR_MFMA 2u   /* force the matrix pipe (ignored together with DSPX_FIR_EXACT)                   */
+#define DSPX_FIR_VECTOR 4u /* force the vector pipe                                                          */
 
 DSPX_API int dspx_version(void);
 /* Number of visible HIP devices (0 if none or the runtime is unusable). */
@@ -86,8 +90,9 @@ DSPX_API int dspx_fir_f64_multi(const double* taps, size_t ntaps, const double* 
 /* Streaming form (no counterpart in the reference, whose lfilter keeps no state between calls,
  * dsp.hpp:356-365): `hist` (nchan x (ntaps-1) doubles, channel c at hist + c*(ntaps-1)) holds the
  * samples that precede x; on return it holds the last ntaps-1 samples of [hist | x], ready for the
- * next chunk.  Zero-filled history makes the first chunk identical to dspx_fir_f64_batched, and
- * chunked calls reproduce one long call bit for bit. */
+ * next chunk.  Runs on the vector pipe unless DSPX_FIR_MFMA is given, so that chunked calls reproduce
+ * one long vector-pipe (DSPX_FIR_VECTOR or DSPX_FIR_EXACT) call bit for bit wherever the chunks are cut;
+ * on the matrix pipe that holds for chunk lengths that are multiples of 4. */
 DSPX_API int dspx_fir_f64_stream(const double* taps, size_t ntaps, double* hist, const double* x, double* y,
                                  size_t nchan, size_t n, size_t stride, unsigned flags);
 

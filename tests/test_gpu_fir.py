@@ -3,8 +3,9 @@ checked against the CPU oracle, the committed reference outputs and the literals
 reference's own tests.
 
 Parity bar (north_star): max|y - y_ref| / max|y_ref| <= 1e-12 for the default FMA mode
-(the only difference from the reference is one rounding per tap instead of two);
-bit-for-bit for DSPX_FIR_EXACT.
+(the only difference from the reference is the rounding of fused multiply-adds and, on the
+matrix pipe, the order of four neighbouring taps); bit-for-bit for DSPX_FIR_EXACT.
+`mfma=None` lets the library pick the pipe, True / False force the matrix / vector pipe.
 """
 import ctypes as C
 
@@ -83,7 +84,8 @@ def test_tap_count_sweep(dsp, oracle, ntaps):
         x = rng.standard_normal(n)
         ref = oracle.lfilter(b, [1.0], x)
         assert np.array_equal(bits(dsp.lfilter(b, x, exact=True)), bits(ref)), (ntaps, n)
-        assert scaled_err(dsp.lfilter(b, x), ref) <= TOL, (ntaps, n)
+        for pipe in (None, True, False):
+            assert scaled_err(dsp.lfilter(b, x, mfma=pipe), ref) <= TOL, (ntaps, n, pipe)
 
 
 def test_empty_inputs(dsp):
@@ -103,6 +105,7 @@ def test_invalid_arguments(dsp):
     assert L.dspx_fir_f64(None, 3, x.ctypes.data, x.ctypes.data, 16, 0) == -1                # NULL taps
     y = np.zeros(16)
     assert L.dspx_fir_f64(b.ctypes.data, 3, x.ctypes.data, y.ctypes.data, 16, 0x80) == -1    # unknown flag
+    assert L.dspx_fir_f64(b.ctypes.data, 3, x.ctypes.data, y.ctypes.data, 16, 2 | 4) == -1   # both pipes forced
     assert L.dspx_fir_f64_batched(b.ctypes.data, 3, x.ctypes.data, y.ctypes.data, 2, 8, 4, 0) == -1  # stride < n
     assert b"stride" in L.dspx_last_error()
 
@@ -120,8 +123,9 @@ def test_unaligned_host_and_device_pointers(dsp, oracle, torch):
     assert xin.data_ptr() % 16 == 8 and out.data_ptr() % 16 == 8
     dsp.fir_device(taps, xin, out=out, exact=True)
     assert np.array_equal(bits(out.cpu().numpy()), bits(ref))
-    dsp.fir_device(taps, xin, out=out)
-    assert scaled_err(out.cpu().numpy(), ref) <= TOL
+    for pipe in (True, False):
+        dsp.fir_device(taps, xin, out=out, mfma=pipe)
+        assert scaled_err(out.cpu().numpy(), ref) <= TOL
 
 
 def test_batched_channels_with_stride(dsp, oracle, torch):
@@ -147,18 +151,22 @@ def test_batched_channels_with_stride(dsp, oracle, torch):
     assert np.all(yh[:, n:] == -7.0)
 
 
+@pytest.mark.parametrize("pipe", [False, True])
 @pytest.mark.parametrize("ntaps", [2, 64, 255, 700])
-def test_history_makes_segments_seamless(dsp, oracle, torch, ntaps):
+def test_history_makes_segments_seamless(dsp, oracle, torch, ntaps, pipe):
     """Filtering a stream in segments, each given the previous ntaps-1 samples as history,
-    reproduces the one-shot result bit for bit (this is what segment sharding relies on)."""
+    reproduces the one-shot result bit for bit (this is what segment sharding relies on).
+    On the vector pipe any cut works; the matrix pipe groups taps in fours by the distance of
+    an output from the start of its call, so there the cuts are multiples of 4 (as the host
+    sharder's are)."""
     n = 10000
     b = oracle.firwin(ntaps, [0.2]) if ntaps > 2 else np.array([0.75, -0.25])
     x = oracle.fill_splitmix(n, dsp.SEED, 31)
     taps = torch.from_numpy(b).cuda()
     xd = torch.from_numpy(x).cuda()
-    whole = dsp.fir_device(taps, xd).cpu().numpy()
+    whole = dsp.fir_device(taps, xd, mfma=pipe).cpu().numpy()
     assert scaled_err(whole, oracle.lfilter(b, [1.0], x)) <= TOL
-    cuts = [0, 1, ntaps // 2 + 1, 2048, 4097, 7777, n]
+    cuts = [0, 4, 4 * (ntaps // 8) + 4, 2048, 4100, 7776, n] if pipe else [0, 1, ntaps // 2 + 1, 2048, 4097, 7777, n]
     out = torch.empty_like(xd)
     for a, e in zip(cuts[:-1], cuts[1:]):
         hist = None
@@ -167,7 +175,7 @@ def test_history_makes_segments_seamless(dsp, oracle, torch, ntaps):
             lead = min(ntaps - 1, a)
             h[ntaps - 1 - lead:] = x[a - lead:a]
             hist = torch.from_numpy(h).cuda()
-        dsp.fir_device(taps, xd[a:e], out=out[a:e], hist=hist)
+        dsp.fir_device(taps, xd[a:e], out=out[a:e], hist=hist, mfma=pipe)
     assert np.array_equal(bits(out.cpu().numpy()), bits(whole))
 
 
@@ -200,9 +208,22 @@ def test_nan_inf_samples_stay_local(dsp, oracle):
     x[1234] = np.inf
     x[4000] = np.nan
     ref = oracle.lfilter(b, [1.0], x)
-    for exact in (True, False):
-        y = dsp.lfilter(b, x, exact=exact)
-        assert np.array_equal(np.isfinite(y), np.isfinite(ref))
+    for exact, pipe in ((True, None), (False, False), (False, True), (False, None)):
+        y = dsp.lfilter(b, x, exact=exact, mfma=pipe)
+        assert np.array_equal(np.isfinite(y), np.isfinite(ref)), (exact, pipe)
+        ok = np.isfinite(ref)
+        assert scaled_err(y[ok], ref[ok]) <= TOL
+    # the same with the bad samples far apart in a long stream and many channels (most tiles stay on the fast path)
+    xl = np.stack([oracle.fill_splitmix(30000, 9, c) for c in range(3)])
+    xl[0, 17] = np.nan
+    xl[1, 29999] = -np.inf
+    xl[2, 12345] = np.inf
+    refl = np.stack([oracle.lfilter(b, [1.0], xl[c]) for c in range(3)])
+    for pipe in (False, True):
+        yl = dsp.lfilter(b, xl, mfma=pipe)
+        assert np.array_equal(np.isfinite(yl), np.isfinite(refl)), pipe
+        ok = np.isfinite(refl)
+        assert scaled_err(yl[ok], refl[ok]) <= TOL
 
 
 @pytest.mark.parametrize("ntaps", [1, 2, 33, 255])

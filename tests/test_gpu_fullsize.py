@@ -97,18 +97,21 @@ def test_long_stream_segment_sharding(env, oracle, golden, numtaps, cutoff, log2
         hist = x[lo - (numtaps - 1): lo] if g else None
         dsp.fir_device(taps, x[lo:hi], out=y2[lo:hi], hist=hist)
     assert dsp.checksum(y2, 0) == whole
-    # uneven cuts that do not fall on tile boundaries
-    cuts = [0, 1, numtaps // 2, 5000, n // 3 + 1, n - 3, n]
-    y2.zero_()
-    for lo, hi in zip(cuts[:-1], cuts[1:]):
-        if lo == 0:
-            hist = None
-        else:
-            lead = min(lo, numtaps - 1)
-            hist = torch.zeros(numtaps - 1, dtype=torch.float64, device="cuda")
-            hist[numtaps - 1 - lead:] = x[lo - lead: lo]
-        dsp.fir_device(taps, x[lo:hi], out=y2[lo:hi], hist=hist)
-    assert dsp.checksum(y2, 0) == whole
+    # uneven cuts that do not fall on tile boundaries: multiples of 4 for the default (matrix) pipe,
+    # which groups taps in fours by an output's distance from the start of its call; any cut on the vector pipe
+    for pipe, cuts in ((None, [0, 4, 4 * (numtaps // 8), 5000, 4 * (n // 12) + 4, n - 4, n]),
+                       (False, [0, 1, numtaps // 2, 5000, n // 3 + 1, n - 3, n])):
+        ref_sum = whole if pipe is None else dsp.checksum(dsp.fir_device(taps, x, mfma=False), 0)
+        y2.zero_()
+        for lo, hi in zip(cuts[:-1], cuts[1:]):
+            if lo == 0:
+                hist = None
+            else:
+                lead = min(lo, numtaps - 1)
+                hist = torch.zeros(numtaps - 1, dtype=torch.float64, device="cuda")
+                hist[numtaps - 1 - lead:] = x[lo - lead: lo]
+            dsp.fir_device(taps, x[lo:hi], out=y2[lo:hi], hist=hist, mfma=pipe)
+        assert dsp.checksum(y2, 0) == ref_sum, pipe
 
 
 def test_shift_invariance_across_tiles(env):
@@ -119,28 +122,37 @@ def test_shift_invariance_across_tiles(env):
     taps = torch.from_numpy(dsp.firwin(255, 0.25)).cuda()
     x = torch.empty(n, dtype=torch.float64, device="cuda")
     dsp.fill_splitmix(x, dsp.SEED, 42)
-    y = dsp.fir_device(taps, x)
-    for k in (1, 7, 1000, 2047, 2049):
-        xs = torch.zeros(n + k, dtype=torch.float64, device="cuda")
-        xs[k:] = x
-        ys = dsp.fir_device(taps, xs)
-        assert torch.equal(ys[k:], y) and bool((ys[:k] == 0).all())
+    for pipe, delays in ((False, (1, 7, 1000, 2047, 2049)), (True, (4, 1000, 2044, 4100))):
+        y = dsp.fir_device(taps, x, mfma=pipe)
+        for k in delays:  # the matrix pipe is invariant under delays that are multiples of 4
+            xs = torch.zeros(n + k, dtype=torch.float64, device="cuda")
+            xs[k:] = x
+            ys = dsp.fir_device(taps, xs, mfma=pipe)
+            assert torch.equal(ys[k:], y) and bool((ys[:k] == 0).all()), (pipe, k)
 
 
 def test_unit_dc_gain_everywhere(env):
     """firwin(..., scale=True) low-pass taps sum to one: a constant input settles to the same
-    constant, identically (same bits) at every steady-state sample of every channel."""
+    constant.  On the vector pipe every steady-state sample of every channel has the same bits;
+    on the matrix pipe the bits depend only on the sample's position modulo 16 (the row of the
+    16x16 product it falls in)."""
     torch, dsp = env
     taps_h = dsp.firwin(255, 0.25)
     taps = torch.from_numpy(taps_h).cuda()
     x = torch.ones((64, 1 << 20), dtype=torch.float64, device="cuda")
-    y = dsp.fir_device(taps, x)
-    steady = y[:, 254:]
+    yv = dsp.fir_device(taps, x, mfma=False)
+    steady = yv[:, 254:]
     v = float(steady[0, 0])
     assert abs(v - 1.0) < 1e-14
     assert bool((steady == v).all())
-    # warm-up samples are the running sums of the taps in ascending order (FMA with 1.0 is exact)
-    assert np.array_equal(bits(y[3, :254].cpu().numpy()), bits(np.cumsum(taps_h)[:254]))
+    # on the vector pipe the warm-up samples are the running sums of the taps in ascending order
+    # (an FMA with 1.0 is exact)
+    assert np.array_equal(bits(yv[3, :254].cpu().numpy()), bits(np.cumsum(taps_h)[:254]))
+    ym = dsp.fir_device(taps, x, mfma=True)
+    assert float((ym[:, 254:] - 1.0).abs().max()) < 1e-14
+    body = ym[:, 256:256 + 16 * 65000].reshape(64, -1, 16)
+    assert bool((body == body[0, 0]).all())
+    assert scaled_err(ym[3, :254].cpu().numpy(), np.cumsum(taps_h)[:254]) <= TOL
 
 
 def test_cwt_bank_65_scales_2e22(env, oracle, golden):

@@ -40,8 +40,8 @@ def test_plan_partitions_the_work(dsp, nchan, n, g):
         spans.sort()
         assert spans[0][0] == 0 and spans[-1][1] == n
         assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
-    if nchan * n >= g * 1000:                          # balanced to within one channel / one sample per device
-        unit = n if nchan >= g else nchan
+    if nchan * n >= g * 1000:                          # balanced to within one channel / a few samples per device
+        unit = n if nchan >= g else 8 * nchan
         assert max(per_dev) - min(per_dev) <= unit
 
 
@@ -51,7 +51,8 @@ def test_plan_device_ranges_are_contiguous(dsp):
     chans = [[c for p in pieces if p[0] == d for c in range(p[1], p[1] + p[2])] for d in range(4)]
     assert sum(chans, []) == list(range(10))
     segs = dsp.fir_plan(1, 1000, 4)                    # fewer channels than devices: segments
-    assert [(p[3], p[4]) for p in segs] == [(0, 250), (250, 250), (500, 250), (750, 250)]
+    assert [(p[3], p[4]) for p in segs] == [(0, 248), (248, 252), (500, 248), (748, 252)]   # starts are multiples of 4
+    assert all(p[3] % 4 == 0 for p in dsp.fir_plan(2, (1 << 25) + 123, 7))
     assert dsp.lib().dspx_fir_plan(1, 10, 0, None, 0) == -1
 
 

@@ -13,6 +13,7 @@ import dsp_amd
 W = {"b255": (4096, 1 << 20, 255), "l101": (1, 1 << 28, 101), "l4095": (1, 1 << 26, 4095), "b255s": (256, 1 << 20, 255),
      "b31": (1024, 1 << 20, 31), "b63": (1024, 1 << 20, 63), "b1023": (256, 1 << 20, 1023), "b101": (2048, 1 << 20, 101), "b256": (4096, 1 << 20, 256), "b240": (4096, 1 << 20, 240), "b512": (2048, 1 << 20, 512),
      "b96": (2048, 1 << 20, 96), "b112": (2048, 1 << 20, 112)}
+MFMA = {"1": True, "0": False}.get(os.environ.get("QB_MFMA"))
 names = sys.argv[1:] or ["b255", "l101", "l4095"]
 for nm in names:
     nchan, n, nt = W[nm]
@@ -21,13 +22,13 @@ for nm in names:
     y = torch.empty_like(x)
     dsp_amd.fill_splitmix(x)
     for _ in range(3):
-        dsp_amd.fir_device(taps, x, out=y)
+        dsp_amd.fir_device(taps, x, out=y, mfma=MFMA)
     torch.cuda.synchronize()
     reps = max(5, int(0.6 / (nchan * n * nt * 2 / 50e12 + 1e-4)))
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):
-        dsp_amd.fir_device(taps, x, out=y)
+        dsp_amd.fir_device(taps, x, out=y, mfma=MFMA)
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
