@@ -50,6 +50,7 @@ def parse_args():
     ap.add_argument("--workload", default="batched255", choices=sorted(WORKLOADS) + ["cwt65"])
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--exact", action="store_true", help="DSPX_FIR_EXACT arithmetic (separate mul/add)")
+    ap.add_argument("--vector", action="store_true", help="force the vector-pipe kernel (DSPX_FIR_VECTOR)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-samples", type=int, default=1 << 27, help="samples of the workload the CPU baseline filters")
     return ap.parse_args()
@@ -138,7 +139,8 @@ def run_cwt(args, rank, world, dev, dist):
                    "arithmetic": "exact (mul+add)" if args.exact else "fma"},
         "roofline": {"bound": "mfma", "achieved": flops / sec / 1e12, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
                      "frac": flops / sec / 1e12 / PEAK_FP64_TFLOPS, "traffic": load_traffic("cwt65"),
-                     "kernel": "fir_f64_kernel (bank mode)", "kernel_ms": kern_ms,
+                     "kernel": "fir_f64_mfma_kernel + fir_f64_kernel (bank mode; rows of >= 160 taps on the matrix pipe)",
+                     "kernel_ms": kern_ms,
                      "note": "FP64 FMA; algorithmic flops = 2 * sum of per-scale tap counts per input sample"},
         "roofline_other": {"bound": "hbm", "achieved": bytes_alg / sec / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                            "frac": bytes_alg / sec / 1e9 / PEAK_HBM_GBS, "traffic": load_traffic("cwt65")},
@@ -215,7 +217,7 @@ def main() -> None:
     torch.cuda.synchronize()
 
     def step():
-        dsp_amd.fir_device(taps, x, out=y, exact=args.exact)
+        dsp_amd.fir_device(taps, x, out=y, exact=args.exact, mfma=False if args.vector else None)
 
     def fence():
         torch.cuda.synchronize()
@@ -242,18 +244,21 @@ def main() -> None:
     dt_max, kern_ms_max = float(t[0]), float(t[1])
 
     if rank == 0:
+        matrix = not args.exact and not args.vector and numtaps >= 160
+        kernel_name = "fir_f64_mfma_kernel (v_mfma_f64_16x16x4_f64)" if matrix else "fir_f64_kernel (v_fma_f64)"
         outputs_per_launch = nchan * n
         flops = 2.0 * numtaps * outputs_per_launch
         bytes_alg = 16.0 * outputs_per_launch
         sec = kern_ms_max / 1e3
         fp64 = {"bound": "mfma", "achieved": flops / sec / 1e12, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
                 "frac": flops / sec / 1e12 / PEAK_FP64_TFLOPS, "traffic": load_traffic(args.workload),
-                "kernel": "fir_f64_kernel", "kernel_ms": kern_ms_max,
-                "note": "FP64 FMA on the vector ALU; on MI355X the FP64 MFMA peak equals the FP64 vector peak "
-                        "(78.6 TFLOP/s), so one number bounds both. algorithmic flops = 2*ntaps per output"}
+                "kernel": kernel_name, "kernel_ms": kern_ms_max,
+                "note": "MI355X FP64 peak: matrix pipe = vector pipe = 78.6 TFLOP/s, so one number bounds both kernels. "
+                        "algorithmic flops = 2*ntaps per output (the Toeplitz-block kernel's multiplies by zero taps "
+                        "are not counted)"}
         hbm = {"bound": "hbm", "achieved": bytes_alg / sec / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                "frac": bytes_alg / sec / 1e9 / PEAK_HBM_GBS, "traffic": load_traffic(args.workload),
-               "kernel": "fir_f64_kernel", "kernel_ms": kern_ms_max,
+               "kernel": kernel_name, "kernel_ms": kern_ms_max,
                "note": "algorithmic bytes = 16 per output (8 read + 8 written)"}
         # the binding roof is the one that allows fewer samples per second
         fp64_roof_gs = PEAK_FP64_TFLOPS * 1e12 / (2.0 * numtaps) / 1e9
@@ -273,7 +278,7 @@ def main() -> None:
             "dtype": "f64",
             "data": "synthetic (splitmix64 uniform [-1,1), generated on device, resident in HBM)",
             "config": {"workload": desc, "nchan_per_gpu": nchan, "samples_per_channel": n, "ntaps": numtaps,
-                       "arithmetic": "exact (mul+add)" if args.exact else "fma",
+                       "arithmetic": "exact (mul+add)" if args.exact else ("fma, matrix pipe" if matrix else "fma, vector pipe"),
                        "sharding": "none" if world == 1 else ("channels" if args.scaling == "strong" else "independent batch per GPU")},
             "roofline": primary,
             "roofline_other": secondary,

@@ -15,7 +15,7 @@ extern thread_local std::string g_last_error;
 int fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
 
 // Taps from which the FP64 matrix pipe is faster than the vector pipe (measured on MI355X).
-constexpr size_t kMatrixPipeMinTaps = 32;
+constexpr size_t kMatrixPipeMinTaps = 160;
 
 inline int check_flags(unsigned flags) {
     if (flags & ~(DSPX_FIR_EXACT | DSPX_FIR_MFMA | DSPX_FIR_VECTOR))

@@ -99,6 +99,7 @@ struct dspx_cwt_bank {
     double* d_taps = nullptr;
     dspx::BankRow* d_rows = nullptr;
     std::vector<size_t> result_row;  // descriptor -> row of the caller's result
+    std::vector<int> row_taps;       // descriptor -> tap count (descending)
 };
 
 namespace {
@@ -128,6 +129,7 @@ int make_bank(const Tables& t, const double* psi, const std::vector<size_t>& pic
         if (taps.size() & 1) taps.push_back(0.0);  // keep every row's taps 16-byte aligned
         rows.push_back(d);
         bank->result_row.push_back(result_row[i]);
+        bank->row_taps.push_back(d.ntaps);
     }
     bank->nrows = rows.size();
     bank->total_taps = 0;
@@ -156,29 +158,36 @@ int apply_bank(const dspx_cwt_bank* bank, const double* d_signal, size_t n, doub
     if (n == 0) return fail(DSPX_ERR_INVALID, "The size of signal must be greater than 0.");
     if (!d_signal || !d_result) return fail(DSPX_ERR_INVALID, "NULL pointer");
     if (row_stride < n) return fail(DSPX_ERR_INVALID, "row_stride (%zu) < n (%zu)", row_stride, n);
-    // One rule for every bank, whatever rows it holds, so that a row's bits do not depend on which other
-    // rows share its launch (scale sharding over GPUs must not change results).
-    const bool mfma = dspx::use_matrix_pipe(flags, dspx::kMatrixPipeMinTaps);
-    const size_t stride = (size_t)(mfma ? dspx::fir_mfma_bank_stride() : dspx::fir_bank_stride());
-    const size_t tiles_per_row = (n + stride - 1) / stride;
-    const size_t run = (tiles_per_row + 7) / 8;  // tiles per row and XCD
-    const size_t max_rows = 0x7fffffffull / (8 * run);
-    if (max_rows == 0) return fail(DSPX_ERR_INVALID, "signal too long for one launch: %zu", n);
     const bool vec2 = dspx::aligned16(d_signal) && dspx::aligned16(d_result) && (row_stride % 2 == 0);
-    for (size_t r0 = 0; r0 < bank->nrows; r0 += max_rows) {
-        const size_t nr = std::min(max_rows, bank->nrows - r0);
-        dspx::FirShape s{};
-        s.y_stride = row_stride;
-        s.n = (long long)n;
-        s.tiles_per_chan = (unsigned)tiles_per_row;
-        s.total_tiles = (unsigned)(nr * 8 * run);  // workgroups; those past a row's last tile exit at once
-        dspx::set_divider(s, (unsigned)run);
-        if (mfma)
-            DSPX_HIP(dspx::launch_fir_mfma_bank_f64(bank->d_taps, bank->d_rows + r0, d_signal, d_result, s, vec2,
-                                                    stream));
-        else
-            DSPX_HIP(dspx::launch_fir_bank_f64(bank->d_taps, bank->d_rows + r0, d_signal, d_result, s,
-                                               (flags & DSPX_FIR_EXACT) != 0, vec2, stream));
+    // Each row runs on the pipe its own tap count selects, whatever other rows the bank holds, so that a
+    // row's bits do not depend on how scales are sharded.  Rows are stored longest first: the matrix-pipe
+    // rows are a prefix of the descriptor array.
+    size_t split = 0;
+    while (split < bank->nrows && dspx::use_matrix_pipe(flags, (size_t)bank->row_taps[split])) ++split;
+    for (int part = 0; part < 2; ++part) {
+        const bool mfma = part == 0;
+        const size_t first = mfma ? 0 : split, count = mfma ? split : bank->nrows - split;
+        if (count == 0) continue;
+        const size_t stride = (size_t)(mfma ? dspx::fir_mfma_bank_stride() : dspx::fir_bank_stride());
+        const size_t tiles_per_row = (n + stride - 1) / stride;
+        const size_t run = (tiles_per_row + 7) / 8;  // tiles per row and XCD
+        const size_t max_rows = 0x7fffffffull / (8 * run);
+        if (max_rows == 0) return fail(DSPX_ERR_INVALID, "signal too long for one launch: %zu", n);
+        for (size_t r0 = 0; r0 < count; r0 += max_rows) {
+            const size_t nr = std::min(max_rows, count - r0);
+            dspx::FirShape s{};
+            s.y_stride = row_stride;
+            s.n = (long long)n;
+            s.tiles_per_chan = (unsigned)tiles_per_row;
+            s.total_tiles = (unsigned)(nr * 8 * run);  // workgroups; those past a row's last tile exit at once
+            dspx::set_divider(s, (unsigned)run);
+            if (mfma)
+                DSPX_HIP(dspx::launch_fir_mfma_bank_f64(bank->d_taps, bank->d_rows + first + r0, d_signal, d_result,
+                                                        s, vec2, stream));
+            else
+                DSPX_HIP(dspx::launch_fir_bank_f64(bank->d_taps, bank->d_rows + first + r0, d_signal, d_result, s,
+                                                   (flags & DSPX_FIR_EXACT) != 0, vec2, stream));
+        }
     }
     return DSPX_OK;
 }

@@ -291,8 +291,8 @@ __global__ __launch_bounds__(kBlock) void fir_f64_kernel(const double* __restric
 // adds, to output i0 + m of every segment, the four taps d+m-3 .. d+m.  A is the same 16x4
 // Toeplitz block for every segment and every i0 (one LDS read per step from a zero-padded copy
 // of the stage's taps); B is four consecutive input samples of each segment (one LDS read per
-// product).  A stage of S taps takes floor((S+2)/4) + 4 steps: the band is about S + 16 columns
-// wide instead of S, so 6 % of the multiplies are by zero at 256 taps.
+// product).  A filter of N taps takes floor((N+2)/4) + 4 steps: the band is about N + 16 columns
+// wide instead of N, so 6 % of the multiplies are by zero at 255 taps and 0.4 % at 4095.
 //
 // Why it exists: on random data the chip holds ~2.39 GHz while issuing these products but only
 // ~1.9 GHz while issuing v_fma_f64 back to back, so the matrix pipe delivers more FP64 work
@@ -308,10 +308,10 @@ constexpr int kMWaveOut = 16 * kMSeg;          // outputs per wave
 constexpr int kMTile = (kBlock / 64) * kMWaveOut;  // outputs per workgroup (4096)
 constexpr int kMBankStride = kMTile - 2;       // outputs per workgroup in bank mode (two spare values of c)
 constexpr int kMHalo = 256;                    // staged samples in front of the tile (>= taps per stage)
-constexpr int kMStageTaps = 256;
+constexpr int kMStageSteps = (kMHalo + 16) / 4; // steps of four tap offsets one staged window serves (68)
 constexpr int kMSlots = kMHalo + kMTile;
 constexpr int kMPairs = (kMSlots + 2 * (kMSlots / 64)) / 2;   // image: 2 pad doubles per 64 samples
-constexpr int kMTapSlots = kMStageTaps + 40;   // zero-padded stage taps: index j + 15 for j in [-15, S + 18)
+constexpr int kMTapSlots = 4 * kMStageSteps + 24;   // zero-padded stage taps: index j + 15 for j in [-15, S + 22)
 constexpr int kMStageIters = (kMSlots / 2 + kBlock - 1) / kBlock;
 typedef double mfma_d4 __attribute__((ext_vector_type(4)));
 
@@ -385,14 +385,21 @@ __global__ __launch_bounds__(kBlock) void fir_f64_mfma_kernel(const double* __re
     const int a_base = 3 + (lane & 15) - (lane >> 4);
     bool bad = false;
 
-    for (int j0 = 0; j0 < ntaps; j0 += kMStageTaps) {
-        const int S = min(kMStageTaps, ntaps - j0);
-        const int steps = (S + 2) / 4 + 4;
+    // Steps of four tap offsets (d = -12, -8, ...) that cover the whole band, rounded up to an even
+    // count (a surplus step multiplies zero taps only; its samples are staged and checked like the
+    // others).  A stage is up to 68 consecutive steps (what the staged halo reaches): it re-stages the samples those offsets reach and
+    // the taps d-3 .. d+15 they multiply, so stage boundaries cost no extra zero columns.
+    const int total_steps = ntaps ? (((ntaps + 2) / 4 + 4 + 1) & ~1) : 0;
+    const int nstages = (total_steps + kMStageSteps - 1) / kMStageSteps;
+    const int per_stage = nstages ? (((total_steps + nstages - 1) / nstages + 1) & ~1) : 0;  // even split, even count
+    for (int e0 = 0; e0 < total_steps; e0 += per_stage) {
+        const int steps = min(per_stage, total_steps - e0);
+        const int j0 = 4 * e0;  // the stage's first offset is d = j0 - 12
         __syncthreads();  // previous stage fully consumed (and bad_flag initialised)
-        // taps j0 .. j0+S-1 at tapz[15 ..], zeros around them
+        // tapz[i] = tap j0 - 15 + i (zero outside the filter)
         for (int i = tid; i < kMTapSlots; i += kBlock) {
-            const int j = i - 15;
-            tapz[i] = (j >= 0 && j < S) ? tapsc[j0 + j] : 0.0;
+            const int j = j0 - 15 + i;
+            tapz[i] = (j >= 0 && j < ntaps) ? tapsc[j] : 0.0;
         }
         // samples: slot q <- sample pos0 - j0 - kMHalo + q, from the lowest pad group the products read
         const int qlo = (kMHalo - (4 * steps - 16)) & ~63;
@@ -429,28 +436,24 @@ __global__ __launch_bounds__(kBlock) void fir_f64_mfma_kernel(const double* __re
         bad = bad_flag != 0;  // workgroup-uniform
         if (bad) break;
 
-        double a_cur = tapz[a_base];
-        double b_cur[4];
-#pragma unroll
-        for (int ob = 0; ob < 4; ++ob) {
-            const int off = 16 * ob + 12;
-            b_cur[ob] = imgd[b_base + off + 2 * (off >> 6)];
-        }
-        for (int e = 0; e < steps; ++e) {
-            const int en = min(e + 1, steps - 1);  // operands of the next step, fetched under this step's products
-            const double a_nxt = tapz[a_base + 4 * en];
-            double b_nxt[4];
+        // two steps per iteration: ten LDS reads are issued together, then eight products
+        for (int e = 0; e < steps; e += 2) {
+            const double a0 = tapz[a_base + 4 * e];
+            const double a1 = tapz[a_base + 4 * e + 4];
+            double b0[4], b1[4];
 #pragma unroll
             for (int ob = 0; ob < 4; ++ob) {
-                const int off = 16 * ob + 12 - 4 * en;  // i0 - d, a multiple of 4, may be negative
-                b_nxt[ob] = imgd[b_base + off + 2 * (off >> 6)];
+                const int off0 = 16 * ob + 12 - 4 * e;   // i0 - d, a multiple of 4, may be negative
+                const int off1 = off0 - 4;
+                b0[ob] = imgd[b_base + off0 + 2 * (off0 >> 6)];
+                b1[ob] = imgd[b_base + off1 + 2 * (off1 >> 6)];
             }
 #pragma unroll
             for (int ob = 0; ob < 4; ++ob)
-                acc[ob] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_cur, b_cur[ob], acc[ob], 0, 0, 0);
-            a_cur = a_nxt;
+                acc[ob] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0[ob], acc[ob], 0, 0, 0);
 #pragma unroll
-            for (int ob = 0; ob < 4; ++ob) b_cur[ob] = b_nxt[ob];
+            for (int ob = 0; ob < 4; ++ob)
+                acc[ob] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1[ob], acc[ob], 0, 0, 0);
         }
     }
 
