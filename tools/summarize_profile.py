@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Condenses a tools/profile.sh output directory into profiles/<tag>_kernel_stats.csv and
+profiles/<tag>_pmc_summary.json, and refreshes profiles/pmc_traffic.json for the workload.
+   python tools/summarize_profile.py gpurun_out/prof_r01c r01c batched255 <outputs_per_launch> <ntaps>"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+src, tag, workload, outputs, ntaps = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4]), int(sys.argv[5])
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+prof = os.path.join(root, "profiles")
+os.makedirs(prof, exist_ok=True)
+shutil.copy(glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv"))[0], os.path.join(prof, f"{tag}_kernel_stats.csv"))
+out = {"command": "tools/profile.sh: rocprofv3 --kernel-trace --stats, then one --pmc pass per counter group, each around "
+                  "`python3 bench.py --steps 5|2 --warmup 1 --no-cpu-baseline`",
+       "workload": workload, "per_launch": {}, "kernel": None}
+for name in ("sq1", "sq2", "fetch", "write", "grbm"):
+    f = glob.glob(os.path.join(src, name, "*", "*_counter_collection.csv"))[0]
+    agg, disp = collections.defaultdict(float), set()
+    for r in csv.DictReader(open(f)):
+        if "fir_f64" in r["Kernel_Name"]:
+            out["kernel"] = r["Kernel_Name"].split("(")[0]
+            agg[r["Counter_Name"]] += float(r["Counter_Value"])
+            disp.add(r["Dispatch_Id"])
+    for c, v in agg.items():
+        out["per_launch"][c] = v / len(disp)
+pl = out["per_launch"]
+out["derived"] = {
+    "hbm_read_bytes_per_launch": pl["FETCH_SIZE"] * 1024 * 2,
+    "hbm_write_bytes_per_launch": pl["WRITE_SIZE"] * 1024,
+    "note_fetch": "FETCH_SIZE is in KB and counts 64 B per 128-B request for 16-byte-per-lane streaming reads on gfx950: doubled",
+    "algorithmic_bytes_per_launch": 16 * outputs,
+    "algorithmic_flops_per_launch": 2 * ntaps * outputs,
+    "lds_conflict_fraction": pl["SQ_LDS_BANK_CONFLICT"] / max(pl["SQ_LDS_IDX_ACTIVE"], 1),
+    "clock_ghz_from_grbm": None,
+}
+json.dump(out, open(os.path.join(prof, f"{tag}_pmc_summary.json"), "w"), indent=1)
+tpath = os.path.join(prof, "pmc_traffic.json")
+tr = json.load(open(tpath)) if os.path.exists(tpath) else {}
+tr[workload] = {"hbm_bytes_per_launch": out["derived"]["hbm_read_bytes_per_launch"] + out["derived"]["hbm_write_bytes_per_launch"],
+                "source": f"profiles/{tag}_pmc_summary.json (FETCH_SIZE x2 + WRITE_SIZE, KB -> bytes)"}
+json.dump(tr, open(tpath, "w"), indent=1)
+print(open(os.path.join(prof, f"{tag}_kernel_stats.csv")).read()[:700])
+print(json.dumps(out["per_launch"], indent=1))
+print(json.dumps(out["derived"], indent=1))
