@@ -139,7 +139,7 @@ def run_cwt(args, rank, world, dev, dist):
                    "arithmetic": "exact (mul+add)" if args.exact else "fma"},
         "roofline": {"bound": "mfma", "achieved": flops / sec / 1e12, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
                      "frac": flops / sec / 1e12 / PEAK_FP64_TFLOPS, "traffic": load_traffic("cwt65"),
-                     "kernel": "fir_f64_mfma_kernel + fir_f64_kernel (bank mode; rows of >= 160 taps on the matrix pipe)",
+                     "kernel": "fir_f64_mfma_kernel + fir_f64_kernel (bank mode; rows of >= 96 taps on the matrix pipe)",
                      "kernel_ms": kern_ms,
                      "note": "FP64 FMA; algorithmic flops = 2 * sum of per-scale tap counts per input sample"},
         "roofline_other": {"bound": "hbm", "achieved": bytes_alg / sec / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
@@ -244,7 +244,7 @@ def main() -> None:
     dt_max, kern_ms_max = float(t[0]), float(t[1])
 
     if rank == 0:
-        matrix = not args.exact and not args.vector and numtaps >= 160
+        matrix = not args.exact and not args.vector and numtaps >= dsp_amd.MATRIX_PIPE_MIN_TAPS
         kernel_name = "fir_f64_mfma_kernel (v_mfma_f64_16x16x4_f64)" if matrix else "fir_f64_kernel (v_fma_f64)"
         outputs_per_launch = nchan * n
         flops = 2.0 * numtaps * outputs_per_launch

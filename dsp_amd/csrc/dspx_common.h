@@ -15,7 +15,7 @@ extern thread_local std::string g_last_error;
 int fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
 
 // Taps from which the FP64 matrix pipe is faster than the vector pipe (measured on MI355X).
-constexpr size_t kMatrixPipeMinTaps = 160;
+constexpr size_t kMatrixPipeMinTaps = 96;
 
 inline int check_flags(unsigned flags) {
     if (flags & ~(DSPX_FIR_EXACT | DSPX_FIR_MFMA | DSPX_FIR_VECTOR))
@@ -31,6 +31,11 @@ inline bool use_matrix_pipe(unsigned flags, size_t ntaps) {
     if (flags & DSPX_FIR_MFMA) return true;
     return ntaps >= kMatrixPipeMinTaps;
 }
+
+// Row blocks (of 16 outputs) per segment of the matrix-pipe kernel: the 2048-output tile keeps more
+// workgroups resident and wins below kMatrixPipeWideTaps; above, the 4096-output tile reads less LDS per product.
+constexpr size_t kMatrixPipeWideTaps = 224;
+inline int matrix_row_blocks(size_t ntaps) { return ntaps >= kMatrixPipeWideTaps ? 4 : 2; }
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 

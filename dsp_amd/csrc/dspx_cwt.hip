@@ -159,16 +159,24 @@ int apply_bank(const dspx_cwt_bank* bank, const double* d_signal, size_t n, doub
     if (!d_signal || !d_result) return fail(DSPX_ERR_INVALID, "NULL pointer");
     if (row_stride < n) return fail(DSPX_ERR_INVALID, "row_stride (%zu) < n (%zu)", row_stride, n);
     const bool vec2 = dspx::aligned16(d_signal) && dspx::aligned16(d_result) && (row_stride % 2 == 0);
-    // Each row runs on the pipe its own tap count selects, whatever other rows the bank holds, so that a
-    // row's bits do not depend on how scales are sharded.  Rows are stored longest first: the matrix-pipe
-    // rows are a prefix of the descriptor array.
-    size_t split = 0;
-    while (split < bank->nrows && dspx::use_matrix_pipe(flags, (size_t)bank->row_taps[split])) ++split;
-    for (int part = 0; part < 2; ++part) {
-        const bool mfma = part == 0;
-        const size_t first = mfma ? 0 : split, count = mfma ? split : bank->nrows - split;
+    // Each row runs on the pipe and tile its own tap count selects, whatever other rows the bank holds, so
+    // that a row's bits do not depend on how scales are sharded.  Rows are stored longest first: wide-tile
+    // matrix rows, then narrow-tile matrix rows, then vector rows are consecutive runs of the descriptors.
+    size_t first = 0;
+    for (int part = 0; part < 3 && first < bank->nrows; ++part) {
+        const bool mfma = part < 2;
+        const int ob = part == 0 ? 4 : 2;
+        size_t end = first;
+        if (mfma) {
+            while (end < bank->nrows && dspx::use_matrix_pipe(flags, (size_t)bank->row_taps[end]) &&
+                   dspx::matrix_row_blocks((size_t)bank->row_taps[end]) == ob)
+                ++end;
+        } else {
+            end = bank->nrows;
+        }
+        const size_t count = end - first;
         if (count == 0) continue;
-        const size_t stride = (size_t)(mfma ? dspx::fir_mfma_bank_stride() : dspx::fir_bank_stride());
+        const size_t stride = (size_t)(mfma ? dspx::fir_mfma_bank_stride(ob) : dspx::fir_bank_stride());
         const size_t tiles_per_row = (n + stride - 1) / stride;
         const size_t run = (tiles_per_row + 7) / 8;  // tiles per row and XCD
         const size_t max_rows = 0x7fffffffull / (8 * run);
@@ -183,11 +191,12 @@ int apply_bank(const dspx_cwt_bank* bank, const double* d_signal, size_t n, doub
             dspx::set_divider(s, (unsigned)run);
             if (mfma)
                 DSPX_HIP(dspx::launch_fir_mfma_bank_f64(bank->d_taps, bank->d_rows + first + r0, d_signal, d_result,
-                                                        s, vec2, stream));
+                                                        s, ob, vec2, stream));
             else
                 DSPX_HIP(dspx::launch_fir_bank_f64(bank->d_taps, bank->d_rows + first + r0, d_signal, d_result, s,
                                                    (flags & DSPX_FIR_EXACT) != 0, vec2, stream));
         }
+        first = end;
     }
     return DSPX_OK;
 }

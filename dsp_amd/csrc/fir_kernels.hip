@@ -303,29 +303,37 @@ __global__ __launch_bounds__(kBlock) void fir_f64_kernel(const double* __restric
 // taps at the band edges multiply real samples, and 0 * Inf is NaN; so a workgroup whose
 // staged window holds a non-finite sample computes its tile with a plain per-output FMA loop
 // instead, which adds exactly the products the reference adds.
-constexpr int kMSeg = 64;                      // outputs per segment
-constexpr int kMWaveOut = 16 * kMSeg;          // outputs per wave
-constexpr int kMTile = (kBlock / 64) * kMWaveOut;  // outputs per workgroup (4096)
-constexpr int kMBankStride = kMTile - 2;       // outputs per workgroup in bank mode (two spare values of c)
-constexpr int kMHalo = 256;                    // staged samples in front of the tile (>= taps per stage)
+constexpr int kMHalo = 256;                     // staged samples in front of the tile
 constexpr int kMStageSteps = (kMHalo + 16) / 4; // steps of four tap offsets one staged window serves (68)
-constexpr int kMSlots = kMHalo + kMTile;
-constexpr int kMPairs = (kMSlots + 2 * (kMSlots / 64)) / 2;   // image: 2 pad doubles per 64 samples
-constexpr int kMTapSlots = 4 * kMStageSteps + 24;   // zero-padded stage taps: index j + 15 for j in [-15, S + 22)
-constexpr int kMStageIters = (kMSlots / 2 + kBlock - 1) / kBlock;
+constexpr int kMTapSlots = 4 * kMStageSteps + 24;
+// Geometry for OB row blocks of 16 outputs per segment (OB = 4: 4096-output tiles, fewest LDS
+// reads per product; OB = 2: 2048-output tiles, twice the workgroups per CU for short filters).
+template <int OB> struct MGeo {
+    static_assert(OB == 2 || OB == 4, "row blocks per segment");
+    static constexpr int kSeg = 16 * OB;                    // outputs per segment = pad group of the image
+    static constexpr int kPadStep = kSeg + 2;               // doubles between segments in the image
+    static constexpr int kShift = OB == 4 ? 6 : 5;          // log2(kSeg)
+    static constexpr int kWaveOut = 16 * kSeg;              // outputs per wave
+    static constexpr int kTile = (kBlock / 64) * kWaveOut;  // outputs per workgroup
+    static constexpr int kBankStride = kTile - 2;           // bank mode: two spare values of c per tile
+    static constexpr int kSlots = kMHalo + kTile;
+    static constexpr int kPairs = (kSlots + 2 * (kSlots / kSeg)) / 2;  // image: 2 pad doubles per segment length
+    static constexpr int kStageIters = (kSlots / 2 + kBlock - 1) / kBlock;
+};
 typedef double mfma_d4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ bool not_finite(double v) {
     return (__double_as_longlong(v) & 0x7ff0000000000000ll) == 0x7ff0000000000000ll;
 }
 
-template <bool VEC2, bool BANK>
+template <int OB, bool VEC2, bool BANK>
 __global__ __launch_bounds__(kBlock) void fir_f64_mfma_kernel(const double* __restrict__ taps,
                                                                const double* __restrict__ x,
                                                                const double* __restrict__ hist,
                                                                double* __restrict__ y,
                                                                const BankRow* __restrict__ bank, FirShape s) {
-    __shared__ double2 img[kMPairs];
+    using G = MGeo<OB>;
+    __shared__ double2 img[G::kPairs];
     __shared__ double tapz[kMTapSlots];
     __shared__ int bad_flag;
     const int tid = threadIdx.x;
@@ -356,7 +364,7 @@ __global__ __launch_bounds__(kBlock) void fir_f64_mfma_kernel(const double* __re
     double* __restrict__ yrow;
     if constexpr (BANK) {
         const BankRow row = bank[chan];
-        tile_start = (long long)tile * kMBankStride;
+        tile_start = (long long)tile * G::kBankStride;
         odd = row.advance & 1;
         pos0 = tile_start + row.advance - odd;
         ntaps = row.ntaps;
@@ -365,7 +373,7 @@ __global__ __launch_bounds__(kBlock) void fir_f64_mfma_kernel(const double* __re
         tapsc = taps + row.taps_off;
         yrow = y + row.out_off * s.y_stride;
     } else {
-        tile_start = (long long)tile * kMTile;
+        tile_start = (long long)tile * G::kTile;
         pos0 = tile_start;
         ntaps = s.ntaps;
         xc = x + (unsigned long long)chan * s.x_stride;
@@ -374,14 +382,14 @@ __global__ __launch_bounds__(kBlock) void fir_f64_mfma_kernel(const double* __re
         yrow = y + (unsigned long long)chan * s.y_stride;
     }
 
-    mfma_d4 acc[4];
+    mfma_d4 acc[OB];
 #pragma unroll
-    for (int ob = 0; ob < 4; ++ob) acc[ob] = mfma_d4{0.0, 0.0, 0.0, 0.0};
+    for (int ob = 0; ob < OB; ++ob) acc[ob] = mfma_d4{0.0, 0.0, 0.0, 0.0};
     if (tid == 0) bad_flag = 0;
 
     const double* imgd = reinterpret_cast<const double*>(img);
     // lane (k = lane >> 4, n = lane & 15): image address of sample seg(n) + k, and tap slot of m - k at d = -12
-    const int b_base = (kMHalo + wave * kMWaveOut) / 64 * 66 + 66 * (lane & 15) + (lane >> 4);
+    const int b_base = (kMHalo + wave * G::kWaveOut) / G::kSeg * G::kPadStep + G::kPadStep * (lane & 15) + (lane >> 4);
     const int a_base = 3 + (lane & 15) - (lane >> 4);
     bool bad = false;
 
@@ -402,24 +410,24 @@ __global__ __launch_bounds__(kBlock) void fir_f64_mfma_kernel(const double* __re
             tapz[i] = (j >= 0 && j < ntaps) ? tapsc[j] : 0.0;
         }
         // samples: slot q <- sample pos0 - j0 - kMHalo + q, from the lowest pad group the products read
-        const int qlo = (kMHalo - (4 * steps - 16)) & ~63;
-        const int npairs = (kMSlots - qlo) / 2;
+        const int qlo = (kMHalo - (4 * steps - 16)) & ~(G::kSeg - 1);
+        const int npairs = (G::kSlots - qlo) / 2;
         const long long g_lo = pos0 - j0 - kMHalo + qlo;
-        double2* stage = img + (qlo >> 1) + (qlo >> 6);
+        double2* stage = img + (qlo >> 1) + (qlo >> G::kShift);
         bool mine_bad = false;
-        if (g_lo >= 0 && g_lo + (kMSlots - qlo) <= n) {  // interior tile: no edge tests
+        if (g_lo >= 0 && g_lo + (G::kSlots - qlo) <= n) {  // interior tile: no edge tests
             const double* __restrict__ src = xc + g_lo;
 #pragma unroll
-            for (int i = 0; i < kMStageIters; ++i) {
+            for (int i = 0; i < G::kStageIters; ++i) {
                 const int pi = tid + i * kBlock;
-                if (i < kMStageIters - 1 || pi < npairs) {
+                if (i < G::kStageIters - 1 || pi < npairs) {
                     double2 v;
                     if constexpr (VEC2)
                         v = reinterpret_cast<const double2*>(src)[pi];
                     else
                         v = make_double2(src[2 * pi], src[2 * pi + 1]);
                     mine_bad = mine_bad || not_finite(v.x) || not_finite(v.y);
-                    stage[pi + (pi >> 5)] = v;
+                    stage[pi + (pi >> (G::kShift - 1))] = v;
                 }
             }
         } else {
@@ -428,7 +436,7 @@ __global__ __launch_bounds__(kBlock) void fir_f64_mfma_kernel(const double* __re
                 const double2 v = make_double2(sample_at(xc, hc, g_lo + 2 * pi, n, ntaps),
                                                sample_at(xc, hc, g_lo + 2 * pi + 1, n, ntaps));
                 mine_bad = mine_bad || not_finite(v.x) || not_finite(v.y);
-                stage[pi + (pi >> 5)] = v;
+                stage[pi + (pi >> (G::kShift - 1))] = v;
             }
         }
         if (mine_bad) bad_flag = 1;
@@ -440,26 +448,26 @@ __global__ __launch_bounds__(kBlock) void fir_f64_mfma_kernel(const double* __re
         for (int e = 0; e < steps; e += 2) {
             const double a0 = tapz[a_base + 4 * e];
             const double a1 = tapz[a_base + 4 * e + 4];
-            double b0[4], b1[4];
+            double b0[OB], b1[OB];
 #pragma unroll
-            for (int ob = 0; ob < 4; ++ob) {
+            for (int ob = 0; ob < OB; ++ob) {
                 const int off0 = 16 * ob + 12 - 4 * e;   // i0 - d, a multiple of 4, may be negative
                 const int off1 = off0 - 4;
-                b0[ob] = imgd[b_base + off0 + 2 * (off0 >> 6)];
-                b1[ob] = imgd[b_base + off1 + 2 * (off1 >> 6)];
+                b0[ob] = imgd[b_base + off0 + 2 * (off0 >> G::kShift)];
+                b1[ob] = imgd[b_base + off1 + 2 * (off1 >> G::kShift)];
             }
 #pragma unroll
-            for (int ob = 0; ob < 4; ++ob)
+            for (int ob = 0; ob < OB; ++ob)
                 acc[ob] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0[ob], acc[ob], 0, 0, 0);
 #pragma unroll
-            for (int ob = 0; ob < 4; ++ob)
+            for (int ob = 0; ob < OB; ++ob)
                 acc[ob] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1[ob], acc[ob], 0, 0, 0);
         }
     }
 
     double* __restrict__ yt = yrow + tile_start;
     const long long left = n - tile_start;
-    constexpr int kOutputs = BANK ? kMBankStride : kMTile;
+    constexpr int kOutputs = BANK ? G::kBankStride : G::kTile;
 
     if (bad) {
         // A non-finite sample is in reach of this tile: add exactly the products the reference adds,
@@ -488,24 +496,24 @@ __global__ __launch_bounds__(kBlock) void fir_f64_mfma_kernel(const double* __re
     // ---- accumulators -> LDS -> coalesced stores.  acc[ob][r] is output 16*ob + (lane >> 4) + 4r of segment lane & 15 ----
     __syncthreads();
     double* outd = reinterpret_cast<double*>(img);
-    const int o_base = wave * (kMWaveOut / 64 * 66) + 66 * (lane & 15) + (lane >> 4);
+    const int o_base = wave * (G::kWaveOut / G::kSeg * G::kPadStep) + G::kPadStep * (lane & 15) + (lane >> 4);
 #pragma unroll
-    for (int ob = 0; ob < 4; ++ob) {
+    for (int ob = 0; ob < OB; ++ob) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) outd[o_base + 16 * ob + 4 * r] = acc[ob][r];
     }
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < kMTile / 2 / kBlock; ++i) {
+    for (int i = 0; i < G::kTile / 2 / kBlock; ++i) {
         const int pi = tid + i * kBlock;
-        double2 o = img[pi + (pi >> 5)];
+        double2 o = img[pi + (pi >> (G::kShift - 1))];
         if constexpr (BANK) {
             // (c[i+1] - c[i]) * factor, shifted by one when the advance was rounded down
-            const int pn = min(pi + 1, kMTile / 2 - 1);
-            const double2 c23 = img[pn + (pn >> 5)];
+            const int pn = min(pi + 1, G::kTile / 2 - 1);
+            const double2 c23 = img[pn + (pn >> (G::kShift - 1))];
             o = odd ? make_double2((c23.x - o.y) * post, (c23.y - c23.x) * post)
                     : make_double2((o.y - o.x) * post, (c23.x - o.y) * post);
-            if (2 * pi >= kMBankStride) continue;
+            if (2 * pi >= G::kBankStride) continue;
         }
         if (2 * pi + 1 < left) {
             if constexpr (VEC2)
@@ -553,30 +561,36 @@ __global__ __launch_bounds__(256) void checksum_kernel(const double* __restrict_
 }  // namespace
 
 int fir_tile() { return kTile; }
-int fir_mfma_tile() { return kMTile; }
-int fir_mfma_bank_stride() { return kMBankStride; }
+int fir_mfma_tile(int row_blocks) { return row_blocks == 2 ? MGeo<2>::kTile : MGeo<4>::kTile; }
+int fir_mfma_bank_stride(int row_blocks) { return row_blocks == 2 ? MGeo<2>::kBankStride : MGeo<4>::kBankStride; }
+
+template <int OB, bool BANK>
+static void launch_mfma_variant(const double* taps, const double* x, const double* hist, double* y, const BankRow* bank,
+                                const FirShape& shape, bool vec2, hipStream_t stream) {
+    const dim3 grid(shape.total_tiles), block(kBlock);
+    if (vec2)
+        hipLaunchKernelGGL((fir_f64_mfma_kernel<OB, true, BANK>), grid, block, 0, stream, taps, x, hist, y, bank, shape);
+    else
+        hipLaunchKernelGGL((fir_f64_mfma_kernel<OB, false, BANK>), grid, block, 0, stream, taps, x, hist, y, bank, shape);
+}
 
 hipError_t launch_fir_mfma_f64(const double* taps, const double* x, const double* hist, double* y,
-                               const FirShape& shape, bool vec2, hipStream_t stream) {
+                               const FirShape& shape, int row_blocks, bool vec2, hipStream_t stream) {
     if (shape.total_tiles == 0) return hipSuccess;
-    const dim3 grid(shape.total_tiles), block(kBlock);
-    const BankRow* none = nullptr;
-    if (vec2)
-        hipLaunchKernelGGL((fir_f64_mfma_kernel<true, false>), grid, block, 0, stream, taps, x, hist, y, none, shape);
+    if (row_blocks == 2)
+        launch_mfma_variant<2, false>(taps, x, hist, y, nullptr, shape, vec2, stream);
     else
-        hipLaunchKernelGGL((fir_f64_mfma_kernel<false, false>), grid, block, 0, stream, taps, x, hist, y, none, shape);
+        launch_mfma_variant<4, false>(taps, x, hist, y, nullptr, shape, vec2, stream);
     return hipGetLastError();
 }
 
 hipError_t launch_fir_mfma_bank_f64(const double* taps, const BankRow* bank, const double* x, double* y,
-                                    const FirShape& shape, bool vec2, hipStream_t stream) {
+                                    const FirShape& shape, int row_blocks, bool vec2, hipStream_t stream) {
     if (shape.total_tiles == 0) return hipSuccess;
-    const dim3 grid(shape.total_tiles), block(kBlock);
-    const double* none = nullptr;
-    if (vec2)
-        hipLaunchKernelGGL((fir_f64_mfma_kernel<true, true>), grid, block, 0, stream, taps, x, none, y, bank, shape);
+    if (row_blocks == 2)
+        launch_mfma_variant<2, true>(taps, x, nullptr, y, bank, shape, vec2, stream);
     else
-        hipLaunchKernelGGL((fir_f64_mfma_kernel<false, true>), grid, block, 0, stream, taps, x, none, y, bank, shape);
+        launch_mfma_variant<4, true>(taps, x, nullptr, y, bank, shape, vec2, stream);
     return hipGetLastError();
 }
 
