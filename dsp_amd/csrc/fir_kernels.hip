@@ -393,11 +393,11 @@ __global__ __launch_bounds__(kBlock) void fir_f64_mfma_kernel(const double* __re
     const int a_base = 3 + (lane & 15) - (lane >> 4);
     bool bad = false;
 
-    // Steps of four tap offsets (d = -12, -8, ...) that cover the whole band, rounded up to an even
-    // count (a surplus step multiplies zero taps only; its samples are staged and checked like the
-    // others).  A stage is up to 68 consecutive steps (what the staged halo reaches): it re-stages the samples those offsets reach and
-    // the taps d-3 .. d+15 they multiply, so stage boundaries cost no extra zero columns.
-    const int total_steps = ntaps ? (((ntaps + 2) / 4 + 4 + 1) & ~1) : 0;
+    // Steps of four tap offsets (d = -12, -8, ...) that cover the whole band.  A stage is up to 68
+    // consecutive steps (what the staged halo reaches), an even number of them except in the last stage:
+    // it re-stages the samples those offsets reach and the taps d-3 .. d+15 they multiply, so stage
+    // boundaries cost no extra zero columns.
+    const int total_steps = ntaps ? (ntaps + 2) / 4 + 4 : 0;
     const int nstages = (total_steps + kMStageSteps - 1) / kMStageSteps;
     const int per_stage = nstages ? (((total_steps + nstages - 1) / nstages + 1) & ~1) : 0;  // even split, even count
     for (int e0 = 0; e0 < total_steps; e0 += per_stage) {
@@ -445,7 +445,7 @@ __global__ __launch_bounds__(kBlock) void fir_f64_mfma_kernel(const double* __re
         if (bad) break;
 
         // two steps per iteration: ten LDS reads are issued together, then eight products
-        for (int e = 0; e < steps; e += 2) {
+        for (int e = 0; e + 1 < steps; e += 2) {
             const double a0 = tapz[a_base + 4 * e];
             const double a1 = tapz[a_base + 4 * e + 4];
             double b0[OB], b1[OB];
@@ -462,6 +462,19 @@ __global__ __launch_bounds__(kBlock) void fir_f64_mfma_kernel(const double* __re
 #pragma unroll
             for (int ob = 0; ob < OB; ++ob)
                 acc[ob] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1[ob], acc[ob], 0, 0, 0);
+        }
+        if (steps & 1) {  // the band's last step
+            const int e = steps - 1;
+            const double a0 = tapz[a_base + 4 * e];
+            double b0[OB];
+#pragma unroll
+            for (int ob = 0; ob < OB; ++ob) {
+                const int off0 = 16 * ob + 12 - 4 * e;
+                b0[ob] = imgd[b_base + off0 + 2 * (off0 >> G::kShift)];
+            }
+#pragma unroll
+            for (int ob = 0; ob < OB; ++ob)
+                acc[ob] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0[ob], acc[ob], 0, 0, 0);
         }
     }
 

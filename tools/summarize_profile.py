@@ -7,6 +7,7 @@ import csv
 import glob
 import json
 import os
+import re
 import shutil
 import sys
 
@@ -20,12 +21,15 @@ out = {"command": "tools/profile.sh: rocprofv3 --kernel-trace --stats, then one 
        "workload": workload, "per_launch": {}, "kernel": None}
 for name in ("sq1", "sq2", "fetch", "write", "grbm"):
     f = glob.glob(os.path.join(src, name, "*", "*_counter_collection.csv"))[0]
-    agg, disp = collections.defaultdict(float), set()
+    agg, disp, spans = collections.defaultdict(float), set(), {}
     for r in csv.DictReader(open(f)):
         if "fir_f64" in r["Kernel_Name"]:
-            out["kernel"] = r["Kernel_Name"].split("(")[0]
+            out["kernel"] = re.search(r"fir_f64\w*(<[^>]*>)?", r["Kernel_Name"]).group(0)
             agg[r["Counter_Name"]] += float(r["Counter_Value"])
             disp.add(r["Dispatch_Id"])
+            spans[r["Dispatch_Id"]] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+    if name == "grbm":
+        out["grbm_pass_avg_launch_ns"] = sum(spans.values()) / len(spans)
     for c, v in agg.items():
         out["per_launch"][c] = v / len(disp)
 pl = out["per_launch"]
@@ -36,7 +40,8 @@ out["derived"] = {
     "algorithmic_bytes_per_launch": 16 * outputs,
     "algorithmic_flops_per_launch": 2 * ntaps * outputs,
     "lds_conflict_fraction": pl["SQ_LDS_BANK_CONFLICT"] / max(pl["SQ_LDS_IDX_ACTIVE"], 1),
-    "clock_ghz_from_grbm": None,
+    "clock_ghz_from_grbm": pl["GRBM_GUI_ACTIVE"] / 8 / out["grbm_pass_avg_launch_ns"],
+    "note_clock": "GRBM_GUI_ACTIVE sums the 8 XCDs; divided by 8 and by the launch duration in the same pass",
 }
 json.dump(out, open(os.path.join(prof, f"{tag}_pmc_summary.json"), "w"), indent=1)
 tpath = os.path.join(prof, "pmc_traffic.json")
@@ -45,5 +50,4 @@ tr[workload] = {"hbm_bytes_per_launch": out["derived"]["hbm_read_bytes_per_launc
                 "source": f"profiles/{tag}_pmc_summary.json (FETCH_SIZE x2 + WRITE_SIZE, KB -> bytes)"}
 json.dump(tr, open(tpath, "w"), indent=1)
 print(open(os.path.join(prof, f"{tag}_kernel_stats.csv")).read()[:700])
-print(json.dumps(out["per_launch"], indent=1))
 print(json.dumps(out["derived"], indent=1))
