@@ -11,8 +11,9 @@ batch of that size (weak scaling; channels are independent, so there is no data-
 collective); `--scaling strong` shards the 4096 channels over the ranks instead.
 
 Rank 0 prints ONE JSON line with the metric, the roofline of the FIR kernel (per-launch HIP
-events on the launch stream) and, at N = 1, the CPU baseline (the oracle's single-threaded
-restatement of the reference loop, timed on a bounded sample of the same workload).
+events on the launch stream) and, at N = 1, the CPU baseline (the reference's own single-threaded
+loop when oracle/_ref holds its compiled header, else the oracle's restatement of it, timed on a bounded
+sample of the same workload).
 """
 from __future__ import annotations
 
@@ -51,6 +52,8 @@ def parse_args():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--exact", action="store_true", help="DSPX_FIR_EXACT arithmetic (separate mul/add)")
     ap.add_argument("--vector", action="store_true", help="force the vector-pipe kernel (DSPX_FIR_VECTOR)")
+    ap.add_argument("--allgather", action="store_true",
+                    help="with --scaling strong and N > 1: also time an all-gather of the result shards (reported apart)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-samples", type=int, default=1 << 27, help="samples of the workload the CPU baseline filters")
     return ap.parse_args()
@@ -60,33 +63,54 @@ def shard(workload: str, rank: int, world: int, scaling: str):
     """(channels of this rank, global index of its first channel, outputs per step over all ranks)."""
     nchan_total, n, _, _, _ = WORKLOADS[workload]
     if scaling == "strong":
-        lo, hi = nchan_total * rank // world, nchan_total * (rank + 1) // world
+        lo, hi = nchan_total * rank // world, nchan_total * (rank + 1) // world   # == dsp_amd.channel_range
         return hi - lo, lo, nchan_total * n
     return nchan_total, rank * nchan_total, nchan_total * world * n
 
 
 def cpu_baseline(taps: np.ndarray, n: int, nsamples: int, y_gpu) -> dict:
-    """Times oracle/fir_oracle.c (single thread) on whole channels of the workload, and, since the
-    CPU result is at hand, checks the GPU output of the same channels against it."""
-    from oracle.pyoracle import SEED, Oracle
+    """Times the CPU loop (single thread) on whole channels of the workload, and, since the CPU result
+    is at hand, checks the GPU output of the same channels against it.  The loop is the reference's own
+    dsp::lfilter when oracle/_ref/libdsp_ref.so (the unmodified header compiled by oracle/Makefile) is
+    in the tree, else oracle/fir_oracle.c, the restatement that is bit-identical to it.  A second pass
+    runs the same channels on all host cores of this process's share (one channel per thread at a time)."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from oracle.pyoracle import SEED, Oracle, Reference, reference_available
 
     orc = Oracle()
+    cpu, kind, what = orc, "port", "oracle/fir_oracle.c gcc -O2 -ffp-contract=off (bit-identical to the reference loop)"
+    if reference_available():
+        try:
+            cpu, kind = Reference(), "reference"
+            what = "dsp::lfilter of the unmodified reference header (oracle/_ref, g++ -std=c++20 -O2 -ffp-contract=off)"
+        except OSError:
+            pass
     per = min(n, nsamples)
     nchan = max(1, min(nsamples // per, y_gpu.shape[0]))
     x = [orc.fill_splitmix(per, SEED, c * n) for c in range(nchan)]
     ref = []
     t0 = time.perf_counter()
     for c in range(nchan):
-        ref.append(orc.lfilter(taps, [1.0], x[c]))
+        ref.append(cpu.lfilter(taps, [1.0], x[c]))
     dt = time.perf_counter() - t0
     worst = 0.0
     for c in range(nchan):
         got = y_gpu[c, :per].cpu().numpy()
         worst = max(worst, float(np.max(np.abs(got - ref[c])) / max(float(np.max(np.abs(ref[c]))), 1e-300)))
-    return {"value": nchan * per / dt / 1e9, "unit": "GS/s", "cores": 1, "kind": "port",
-            "sample": f"{nchan} channel(s) x {per} samples of the same workload, {taps.size} taps, {dt:.1f} s, "
-                      "oracle/fir_oracle.c gcc -O2 -ffp-contract=off (bit-identical to the reference loop)",
-            "gpu_vs_cpu_max_scaled_err": worst}
+    res = {"value": nchan * per / dt / 1e9, "unit": "GS/s", "cores": 1, "kind": kind,
+           "sample": f"{nchan} channel(s) x {per} samples of the same workload, {taps.size} taps, {dt:.1f} s, {what}",
+           "gpu_vs_cpu_max_scaled_err": worst}
+    cores = min(len(os.sched_getaffinity(0)), int(os.environ.get("OMP_NUM_THREADS", "16")), nchan)
+    if cores > 1:
+        # the reference is single-threaded; independent channels are what a caller would spread over cores
+        with ThreadPoolExecutor(cores) as pool:
+            t0 = time.perf_counter()
+            list(pool.map(lambda c: cpu.lfilter(taps, [1.0], x[c]), range(nchan)))
+            dt_all = time.perf_counter() - t0
+        res["all_cores"] = {"value": nchan * per / dt_all / 1e9, "unit": "GS/s", "cores": cores,
+                            "sample": f"the same {nchan} channels, one channel per thread at a time, {dt_all:.1f} s"}
+    return res
 
 
 def run_cwt(args, rank, world, dev, dist):
@@ -146,21 +170,27 @@ def run_cwt(args, rank, world, dev, dist):
                            "frac": bytes_alg / sec / 1e9 / PEAK_HBM_GBS, "traffic": load_traffic("cwt65")},
     }
     if world == 1 and not args.no_cpu_baseline:
-        from oracle.pyoracle import SEED, Oracle
+        from oracle.pyoracle import SEED, Oracle, Reference, reference_available
 
         orc = Oracle()
+        cpu, kind, what = orc, "port", "oracle/cwt_oracle.c gcc -O2 -ffp-contract=off (bit-identical to the reference loop)"
+        if reference_available():
+            try:
+                cpu, kind = Reference(), "reference"
+                what = "dsp::cwt of the unmodified reference header (oracle/_ref, g++ -std=c++20 -O2 -ffp-contract=off)"
+            except OSError:
+                pass
         m = 1 << 14                               # bounded sample: the first 2^14 samples, all 65 scales
         xs = orc.fill_splitmix(m, SEED, 0)
         t0 = time.perf_counter()
-        ref = orc.cwt(xs, scales, psi, wx)
+        ref = cpu.cwt(xs, scales, psi, wx)
         cdt = time.perf_counter() - t0
         # the transform of a prefix differs from the prefix of the transform near its right edge only
         keep = m - 1100
         got = out[:, :keep].cpu().numpy()
         err = max(float(np.max(np.abs(got[r] - ref[r, :keep])) / np.max(np.abs(ref[r, :keep]))) for r in range(nscales))
-        res["cpu_baseline"] = {"value": m / cdt / 1e9, "unit": "GS/s", "cores": 1, "kind": "port",
-                               "sample": f"first {m} samples, all {nscales} scales, {cdt:.1f} s, oracle/cwt_oracle.c "
-                                         "gcc -O2 -ffp-contract=off (bit-identical to the reference loop)",
+        res["cpu_baseline"] = {"value": m / cdt / 1e9, "unit": "GS/s", "cores": 1, "kind": kind,
+                               "sample": f"first {m} samples, all {nscales} scales, {cdt:.1f} s, {what}",
                                "gpu_vs_cpu_max_scaled_err": err}
     print(json.dumps(res), flush=True)
 
@@ -238,10 +268,23 @@ def main() -> None:
     dt = time.perf_counter() - t0
     kern_ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps)]
 
-    t = torch.tensor([dt, float(np.mean(kern_ms))], dtype=torch.float64, device=dev)
+    # optional exchange step, timed apart from the filter: every rank receives all result shards over RCCL
+    gather_ms = 0.0
+    if args.allgather and world > 1 and args.scaling == "strong":
+        nchan_total = WORKLOADS[args.workload][0]
+        full = dsp_amd.allgather_channels(y, nchan_total)   # warm-up (also sets up the communicator's buffers)
+        del full
+        fence()
+        t0 = time.perf_counter()
+        full = dsp_amd.allgather_channels(y, nchan_total)
+        fence()
+        gather_ms = (time.perf_counter() - t0) * 1e3
+        del full
+
+    t = torch.tensor([dt, float(np.mean(kern_ms)), gather_ms], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt_max, kern_ms_max = float(t[0]), float(t[1])
+    dt_max, kern_ms_max, gather_ms = float(t[0]), float(t[1]), float(t[2])
 
     if rank == 0:
         matrix = not args.exact and not args.vector and numtaps >= dsp_amd.MATRIX_PIPE_MIN_TAPS
@@ -283,6 +326,11 @@ def main() -> None:
             "roofline": primary,
             "roofline_other": secondary,
         }
+        if gather_ms > 0.0:
+            total_bytes = 8.0 * WORKLOADS[args.workload][0] * n
+            out["allgather"] = {"ms": gather_ms, "bytes_received_per_gpu": total_bytes * (world - 1) / world,
+                                "GB/s_per_gpu": total_bytes * (world - 1) / world / gather_ms / 1e6,
+                                "note": "optional all_gather_into_tensor of the result shards (RCCL); not part of value"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(taps_h, n, args.cpu_samples, y)
         print(json.dumps(out), flush=True)

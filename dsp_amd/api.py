@@ -208,3 +208,38 @@ def checksum(t, offset: int = 0) -> int:
     out = torch.zeros(1, dtype=torch.int64, device=t.device)
     check(lib().dspx_checksum_f64_dev(t.data_ptr(), t.numel(), offset & (2**64 - 1), out.data_ptr(), _stream_ptr()))
     return int(out.item()) & (2**64 - 1)
+
+
+def channel_range(nchan_total: int, rank: int, world: int):
+    """Contiguous channel range [lo, hi) of `rank` when `nchan_total` channels are sharded over `world` devices."""
+    return nchan_total * rank // world, nchan_total * (rank + 1) // world
+
+
+def allgather_channels(y_local, nchan_total: int, group=None):
+    """Optional exchange step after a channel-sharded filter: every rank receives the shards of all ranks
+    (one process per GPU; RCCL over xGMI when the process group's backend is "nccl").  `y_local` holds this
+    rank's channels `channel_range(nchan_total, rank, world)` as rows; returns the [nchan_total, n] result.
+    The filter itself needs no collective; this only serves callers that want the whole result on every GPU."""
+    import torch
+    import torch.distributed as dist
+
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    lo, hi = channel_range(nchan_total, rank, world)
+    if y_local.dim() != 2 or y_local.shape[0] != hi - lo:
+        raise ValueError(f"rank {rank} must hold channels [{lo}, {hi}) as rows, got shape {tuple(y_local.shape)}")
+    y_local = y_local.contiguous()
+    n = y_local.shape[1]
+    full = torch.empty((nchan_total, n), dtype=y_local.dtype, device=y_local.device)
+    if nchan_total % world == 0:
+        dist.all_gather_into_tensor(full, y_local, group=group)   # equal shards land in rank order = channel order
+        return full
+    # uneven shards: pad every shard to the largest, gather, then drop the padding rows
+    most = max(channel_range(nchan_total, r, world)[1] - channel_range(nchan_total, r, world)[0] for r in range(world))
+    send = torch.zeros((most, n), dtype=y_local.dtype, device=y_local.device)
+    send[: hi - lo] = y_local
+    recv = torch.empty((world * most, n), dtype=y_local.dtype, device=y_local.device)
+    dist.all_gather_into_tensor(recv, send, group=group)
+    for r in range(world):
+        rlo, rhi = channel_range(nchan_total, r, world)
+        full[rlo:rhi] = recv[r * most: r * most + (rhi - rlo)]
+    return full

@@ -49,6 +49,16 @@ def main():
             ref = np.stack([orc.lfilter(b, [1.0], x[c]) for c in range(nchan)])
             report[name] = {"bit_identical": bool(np.array_equal(t.numpy().view(np.uint64), ref.view(np.uint64))),
                             "covered": int(cnt_t.item()), "total": nchan * n}
+    # the optional exchange step: all-gather of channel shards, even (6 channels) and uneven (5 channels)
+    for nchan in (6, 5):
+        n, ntaps = 777, 21
+        b = orc.firwin(ntaps, [0.3])
+        ref = np.stack([orc.lfilter(b, [1.0], orc.fill_splitmix(n, SEED, c * n)) for c in range(nchan)])
+        lo, hi = dsp_amd.channel_range(nchan, rank, world)
+        full = dsp_amd.allgather_channels(torch.from_numpy(ref[lo:hi].copy()), nchan)
+        ok = torch.tensor([int(np.array_equal(full.numpy().view(np.uint64), ref.view(np.uint64)))])
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)   # every rank must hold the whole result
+        report[f"allgather_{nchan}"] = bool(ok.item())
     # the benchmark's rank -> shard arithmetic and its max-over-ranks reduction
     nch, c0, units = bench.shard("batched255", rank, world, "strong")
     span = torch.tensor([c0, c0 + nch], dtype=torch.int64)

@@ -87,3 +87,4 @@ def test_world_size_2_gloo(dsp):
     assert rep["strong_spans"] == [[0, 2048], [2048, 4096]] and rep["strong_units"] == 4096 << 20
     assert rep["weak"] == [[4096, 0, 2 * (4096 << 20)], [4096, 4096, 2 * (4096 << 20)]]
     assert rep["max_over_ranks"] == 2.0
+    assert rep["allgather_6"] and rep["allgather_5"]
