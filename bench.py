@@ -134,13 +134,13 @@ def run_cwt(args, rank, world, dev, dist):
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        bank.apply(sig, out=out, exact=args.exact)
+        bank.apply(sig, out=out, exact=args.exact, mfma=False if args.vector else None)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     fence()
     t0 = time.perf_counter()
     ev[0].record()
     for i in range(args.steps):
-        bank.apply(sig, out=out, exact=args.exact)
+        bank.apply(sig, out=out, exact=args.exact, mfma=False if args.vector else None)
         ev[i + 1].record()
     fence()
     dt = time.perf_counter() - t0
@@ -163,7 +163,8 @@ def run_cwt(args, rank, world, dev, dist):
                    "arithmetic": "exact (mul+add)" if args.exact else "fma"},
         "roofline": {"bound": "mfma", "achieved": flops / sec / 1e12, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
                      "frac": flops / sec / 1e12 / PEAK_FP64_TFLOPS, "traffic": load_traffic("cwt65"),
-                     "kernel": "fir_f64_mfma_kernel + fir_f64_kernel (bank mode; rows of >= 96 taps on the matrix pipe)",
+                     "kernel": "fir_f64_kernel (bank mode, vector pipe)" if args.vector or args.exact else
+                               "fir_f64_mfma_kernel + fir_f64_kernel (bank mode; rows of >= 96 taps on the matrix pipe)",
                      "kernel_ms": kern_ms,
                      "note": "FP64 FMA; algorithmic flops = 2 * sum of per-scale tap counts per input sample"},
         "roofline_other": {"bound": "hbm", "achieved": bytes_alg / sec / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
