@@ -26,6 +26,7 @@ class Piece(C.Structure):
 SIGNATURES = {
     "dspx_version": (C.c_int, []),
     "dspx_device_count": (C.c_int, []),
+    "dspx_release_staging": (C.c_int, []),
     "dspx_last_error": (C.c_char_p, []),
     "dspx_status_string": (C.c_char_p, [C.c_int]),
     "dspx_firwin_f64": (C.c_int, [C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p]),

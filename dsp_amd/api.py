@@ -24,6 +24,11 @@ def device_count() -> int:
     return int(lib().dspx_device_count())
 
 
+def release_staging() -> int:
+    """Frees the idle staging sets of the host-pointer entry points (dspx_release_staging)."""
+    return int(lib().dspx_release_staging())
+
+
 def _flags(exact: bool, mfma=None) -> int:
     """exact -> DSPX_FIR_EXACT; mfma: None = library's choice, True / False = force the matrix / vector pipe."""
     f = DSPX_FIR_EXACT if exact else DSPX_FIR_FMA
@@ -46,10 +51,16 @@ def firwin(numtaps: int, cutoff, pass_zero: bool = True, scale: bool = True) -> 
     return out[: int(numtaps)]
 
 
-def lfilter(b, x, exact: bool = False, mfma=None) -> np.ndarray:
-    """dsp::lfilter(b, 1.0, x) for host arrays: 1-D x, or 2-D (channels, samples)."""
+def lfilter(b, x, exact: bool = False, mfma=None, out=None) -> np.ndarray:
+    """dsp::lfilter(b, 1.0, x) for host arrays: 1-D x, or 2-D (channels, samples).  `out`, if given, is a
+    C-contiguous float64 array of x's shape that receives the result (as lfilter_ctx_t::result is reused)."""
     b, x = _np_f64(b), _np_f64(x)
-    y = np.empty_like(x)
+    if out is None:
+        y = np.empty_like(x)
+    else:
+        if not (isinstance(out, np.ndarray) and out.dtype == np.float64 and out.flags.c_contiguous and out.shape == x.shape):
+            raise ValueError("out must be a C-contiguous float64 array of x's shape")
+        y = out
     if x.ndim == 1:
         check(lib().dspx_fir_f64(b.ctypes.data, b.size, x.ctypes.data, y.ctypes.data, x.size, _flags(exact, mfma)))
     elif x.ndim == 2:

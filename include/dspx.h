@@ -49,6 +49,10 @@ typedef enum dspx_status {
 DSPX_API int dspx_version(void);
 /* Number of visible HIP devices (0 if none or the runtime is unusable). */
 DSPX_API int dspx_device_count(void);
+/* The host-pointer entry points keep their staging (pinned host buffers, device buffers, streams: up to two
+   idle sets per device, each sized by the largest call it served) between calls, as the reference keeps
+   lfilter_ctx_t::result (dsp.hpp:333, 348-350).  This frees the idle sets; returns how many were freed. */
+DSPX_API int dspx_release_staging(void);
 DSPX_API const char* dspx_last_error(void);
 DSPX_API const char* dspx_status_string(int status);
 

@@ -180,7 +180,8 @@ def test_history_makes_segments_seamless(dsp, oracle, torch, ntaps, pipe):
 
 
 def test_host_path_piece_boundaries(dsp, oracle):
-    """One channel longer than a staging piece (2^24 samples): the pieces are stitched with history."""
+    """One channel much longer than a staging piece (2^21 samples): the pieces are stitched with history
+    and flow through the threaded pipeline."""
     n = (1 << 24) + 4321
     b = oracle.firwin(31, [0.4])
     x = oracle.fill_splitmix(n, dsp.SEED, 0)
@@ -189,6 +190,48 @@ def test_host_path_piece_boundaries(dsp, oracle):
     assert np.array_equal(bits(y), bits(ref))
     y = dsp.lfilter_multi(b, x, ngpus=1)
     assert scaled_err(y, ref) <= TOL
+
+
+def test_host_path_pipeline_shapes(dsp, oracle):
+    """The staged pipeline over the piece shapes it distinguishes: one or two pieces (run in the calling
+    thread), a few pieces (one thread each way), many pieces (two threads each way), many short channels per
+    piece, a long filter whose history is a large part of every row, and two host threads calling at once.
+    The staging sets survive between calls and can be released."""
+    import threading
+
+    b31, b4095 = oracle.firwin(31, [0.4]), oracle.firwin(4095, [0.1])
+    cases = [(1, 1000, b31), (1, (1 << 21) + 5, b31), (1, 5 * (1 << 21) + 3, b31), (1, 9 * (1 << 21) + 1, b31),
+             (3000, 1031, b31), (37, (1 << 17) + 1, b31), (3, (1 << 22) + 7, b4095)]
+    for nchan, n, b in cases:
+        x = np.stack([oracle.fill_splitmix(n, dsp.SEED, c * n) for c in range(nchan)])
+        y = dsp.lfilter(b, x, exact=True)
+        for c in sorted({0, nchan // 2, nchan - 1}):
+            assert np.array_equal(bits(y[c]), bits(oracle.lfilter(b, [1.0], x[c]))), (nchan, n, c)
+        if nchan > 8:   # every channel, cheaply: a channel's output depends on its own input only
+            rows = dsp.lfilter(b, x[::-1].copy(), exact=True)[::-1]
+            assert np.array_equal(bits(rows), bits(y))
+    # streaming state through the same pipeline, chunks longer than a piece
+    n = 3 * (1 << 21) + 11
+    x = oracle.fill_splitmix(n, dsp.SEED, 0)
+    hist = np.zeros(30)
+    ys = np.concatenate([dsp.lfilter_stream(b31, hist, x[:n // 2], exact=True),
+                         dsp.lfilter_stream(b31, hist, x[n // 2:], exact=True)])
+    assert np.array_equal(bits(ys), bits(oracle.lfilter(b31, [1.0], x)))
+    # two callers at once on one device: each gets a staging set of its own
+    xs = [oracle.fill_splitmix(4 * (1 << 21) + k, dsp.SEED, k << 30) for k in range(2)]
+    out = [None, None]
+
+    def call(k):
+        out[k] = dsp.lfilter(b31, xs[k], exact=True)
+
+    th = [threading.Thread(target=call, args=(k,)) for k in range(2)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    for k in range(2):
+        assert np.array_equal(bits(out[k]), bits(oracle.lfilter(b31, [1.0], xs[k])))
+    assert 1 <= dsp.release_staging() <= 2
+    assert dsp.release_staging() == 0
+    assert np.array_equal(bits(dsp.lfilter(b31, xs[0][:5000], exact=True)), bits(out[0][:5000]))
 
 
 def test_splitmix_fill_and_checksum_match_oracle(dsp, oracle, torch):

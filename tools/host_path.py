@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""End-to-end timing of the host-pointer entry points (dspx_fir_f64 / _batched): pageable host
+buffers in, pageable host buffers out, PCIe both ways (development aid; bench.py's value is the
+device-resident rate).   python tools/host_path.py [log2n ...]"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+
+import dsp_amd
+
+taps = dsp_amd.firwin(255, 0.25)
+rng = np.random.default_rng(1)
+for lg in [int(a) for a in sys.argv[1:]] or [20, 24, 27]:
+    n = 1 << lg
+    x = rng.uniform(-1, 1, n)
+    dsp_amd.lfilter(taps, x[: min(n, 1 << 16)])  # context, streams, first-touch
+    best = 1e9
+    for _ in range(3):
+        t0 = time.perf_counter()
+        y = dsp_amd.lfilter(taps, x)
+        best = min(best, time.perf_counter() - t0)
+    reuse = 1e9
+    for _ in range(3):
+        t0 = time.perf_counter()
+        dsp_amd.lfilter(taps, x, out=y)
+        reuse = min(reuse, time.perf_counter() - t0)
+    print(f"lfilter 255 taps, n=2^{lg}: fresh output {best * 1e3:9.2f} ms {n / best / 1e9:6.3f} GS/s | reused output "
+          f"{reuse * 1e3:9.2f} ms {n / reuse / 1e9:6.3f} GS/s ({16 * n / reuse / 1e9:5.1f} GB/s both directions)", flush=True)
