@@ -151,8 +151,6 @@ constexpr int kSlots = 8;
 // small filter).  One call uses an engine exclusively; concurrent calls on a device get engines of their own.
 struct Engine {
     int device = -1;
-    double* d_taps = nullptr;
-    size_t taps_cap = 0;
     Slot slots[kSlots];
 };
 
@@ -173,7 +171,6 @@ void destroy_engine(Engine* e) {
         if (s.d_in) (void)hipFree(s.d_in);
         if (s.d_out) (void)hipFree(s.d_out);
     }
-    if (e->d_taps) (void)hipFree(e->d_taps);
     (void)hipSetDevice(cur);
     delete e;
 }
@@ -241,12 +238,13 @@ int grow_slot(Slot& s, size_t in_doubles, size_t out_doubles) {
     return DSPX_OK;
 }
 
-// Row geometry of a staged piece: [pad | ntaps-1 history samples | len samples], rows 16-byte aligned.
+// Geometry of a staged piece: rows of [pad | ntaps-1 history samples | len samples], 16-byte aligned.
+// The taps travel in front of the rows, so a piece needs one upload.
 struct PieceGeom {
-    size_t hl, hl_pad, in_pitch, out_pitch;
+    size_t hl, hl_pad, in_pitch, out_pitch, taps_pad;
     PieceGeom(size_t ntaps, size_t len)
         : hl(ntaps ? ntaps - 1 : 0), hl_pad((hl + 1) & ~size_t(1)), in_pitch(hl_pad + ((len + 1) & ~size_t(1))),
-          out_pitch((len + 1) & ~size_t(1)) {}
+          out_pitch((len + 1) & ~size_t(1)), taps_pad((ntaps + 1) & ~size_t(1)) {}
 };
 
 // What one call on one device shares between its producer and consumer threads.
@@ -286,13 +284,14 @@ struct Pipeline {
         const Piece& p = (*pieces)[i];
         Slot& s = eng->slots[i % kSlots];
         const PieceGeom g(ntaps, p.len);
-        if (int grc = grow_slot(s, g.in_pitch * p.cnt, g.out_pitch * p.cnt)) return grc;
+        if (int grc = grow_slot(s, g.taps_pad + g.in_pitch * p.cnt, g.out_pitch * p.cnt)) return grc;
+        if (ntaps) std::memcpy(s.pin_in, taps, ntaps * sizeof(double));
         // history: the lead samples that exist in the caller's buffer; before them the caller's
         // initial history (samples s0 .. hl-1 of it when lead == s0 < hl), or zeros
         const size_t lead = std::min(g.hl, p.s0);
         const bool with_hist = (p.s0 > 0 || hist0) && g.hl > 0;
         for (size_t r = 0; r < p.cnt; ++r) {
-            double* row = s.pin_in + r * g.in_pitch;
+            double* row = s.pin_in + g.taps_pad + r * g.in_pitch;
             const double* xr = x + (p.c + r) * stride;
             if (with_hist) {
                 double* h = row + (g.hl_pad - g.hl);
@@ -306,9 +305,11 @@ struct Pipeline {
             }
             std::memcpy(row + g.hl_pad, xr + p.s0, p.len * sizeof(double));
         }
-        DSPX_HIP(hipMemcpyAsync(s.d_in, s.pin_in, g.in_pitch * p.cnt * sizeof(double), hipMemcpyHostToDevice, s.stream));
-        if (int lrc = launch_dev(eng->d_taps, ntaps, s.d_in + g.hl_pad, g.in_pitch,
-                                 with_hist ? s.d_in + (g.hl_pad - g.hl) : nullptr, g.in_pitch, s.d_out, g.out_pitch,
+        DSPX_HIP(hipMemcpyAsync(s.d_in, s.pin_in, (g.taps_pad + g.in_pitch * p.cnt) * sizeof(double),
+                                hipMemcpyHostToDevice, s.stream));
+        const double* d_rows = s.d_in + g.taps_pad;
+        if (int lrc = launch_dev(s.d_in, ntaps, d_rows + g.hl_pad, g.in_pitch,
+                                 with_hist ? d_rows + (g.hl_pad - g.hl) : nullptr, g.in_pitch, s.d_out, g.out_pitch,
                                  p.cnt, p.len, flags, s.stream))
             return lrc;
         DSPX_HIP(hipMemcpyAsync(s.pin_out, s.d_out, g.out_pitch * p.cnt * sizeof(double), hipMemcpyDeviceToHost,
@@ -360,15 +361,6 @@ int run_device(int device, const double* taps, size_t ntaps, const double* hist0
     Pipeline pl{device, eng, taps, hist0, x, y, ntaps, stride, flags, &pieces};
     pl.state.assign(pieces.size(), 0);
     auto body = [&]() -> int {
-        if (ntaps) {
-            if (eng->taps_cap < ntaps) {
-                if (eng->d_taps) DSPX_HIP(hipFree(eng->d_taps));
-                eng->d_taps = nullptr, eng->taps_cap = 0;
-                DSPX_HIP(hipMalloc((void**)&eng->d_taps, ntaps * sizeof(double)));
-                eng->taps_cap = ntaps;
-            }
-            DSPX_HIP(hipMemcpy(eng->d_taps, taps, ntaps * sizeof(double), hipMemcpyHostToDevice));
-        }
         if (pieces.size() <= 2) {
             for (size_t i = 0; i < pieces.size(); ++i)
                 if (int prc = pl.produce(i)) return prc;
