@@ -113,7 +113,7 @@ def cpu_baseline(taps: np.ndarray, n: int, nsamples: int, y_gpu) -> dict:
     return res
 
 
-def run_cwt(args, rank, world, dev, dist):
+def run_cwt(args, rank, world, dev, dist, red_dev):
     """The wavelet-bank workload: every rank transforms its own 2^22-sample signal (weak scaling)."""
     import torch
 
@@ -145,7 +145,7 @@ def run_cwt(args, rank, world, dev, dist):
     fence()
     dt = time.perf_counter() - t0
     kern_ms = float(np.mean([ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps)]))
-    t = torch.tensor([dt, kern_ms], dtype=torch.float64, device=dev)
+    t = torch.tensor([dt, kern_ms], dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     if rank != 0:
@@ -222,14 +222,23 @@ def main() -> None:
 
     import dsp_amd
 
+    # Rehearsal on a one-GPU machine: DSPX_BENCH_BACKEND=gloo DSPX_BENCH_ONE_DEVICE=1 puts every rank on GPU 0
+    # and runs the barrier and the reductions over gloo (RCCL refuses two ranks on one device).
+    backend = os.environ.get("DSPX_BENCH_BACKEND", "nccl")
+    if os.environ.get("DSPX_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    red_dev = dev if backend == "nccl" else torch.device("cpu")   # where the timing reductions live
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend=os.environ.get("DSPX_BENCH_BACKEND", "nccl"), device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
 
     if args.workload == "cwt65":
-        run_cwt(args, rank, world, dev, dist)
+        run_cwt(args, rank, world, dev, dist, red_dev)
         if world > 1:
             dist.barrier()
             dist.destroy_process_group()
@@ -271,7 +280,7 @@ def main() -> None:
 
     # optional exchange step, timed apart from the filter: every rank receives all result shards over RCCL
     gather_ms = 0.0
-    if args.allgather and world > 1 and args.scaling == "strong":
+    if args.allgather and world > 1 and args.scaling == "strong" and backend == "nccl":
         nchan_total = WORKLOADS[args.workload][0]
         full = dsp_amd.allgather_channels(y, nchan_total)   # warm-up (also sets up the communicator's buffers)
         del full
@@ -282,7 +291,7 @@ def main() -> None:
         gather_ms = (time.perf_counter() - t0) * 1e3
         del full
 
-    t = torch.tensor([dt, float(np.mean(kern_ms)), gather_ms], dtype=torch.float64, device=dev)
+    t = torch.tensor([dt, float(np.mean(kern_ms)), gather_ms], dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt_max, kern_ms_max, gather_ms = float(t[0]), float(t[1]), float(t[2])
