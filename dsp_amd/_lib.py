@@ -39,6 +39,12 @@ SIGNATURES = {
                                      C.c_size_t, C.c_int, C.c_uint]),
     "dspx_fir_f64_stream": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
                                       C.c_size_t, C.c_size_t, C.c_uint]),
+    "dspx_lfilter_f64": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t,
+                                   C.c_size_t, C.c_size_t, C.c_uint]),
+    "dspx_lfilter_workspace_bytes": (C.c_size_t, [C.c_size_t, C.c_size_t, C.c_size_t]),
+    "dspx_lfilter_f64_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                       C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                       C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t, C.c_uint, C.c_void_p]),
     "dspx_fir_plan": (C.c_long, [C.c_size_t, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t]),
     "dspx_fir_f64_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
                                    C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_uint, C.c_void_p]),

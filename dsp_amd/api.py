@@ -71,6 +71,50 @@ def lfilter(b, x, exact: bool = False, mfma=None, out=None) -> np.ndarray:
     return y
 
 
+def lfilter_iir(b, a, x, exact: bool = False, mfma=None) -> np.ndarray:
+    """dsp::lfilter(b, a, x) with a recursive part (dsp.hpp:342-371) for host arrays: 1-D x, or 2-D
+    (channels, samples).  a[0] is never read."""
+    b, a, x = _np_f64(b), _np_f64(np.atleast_1d(a)), _np_f64(x)
+    x2 = x.reshape(1, -1) if x.ndim == 1 else x
+    if x2.ndim != 2:
+        raise ValueError("x must be 1-D or 2-D")
+    y = np.empty_like(x2)
+    check(lib().dspx_lfilter_f64(b.ctypes.data, b.size, a.ctypes.data, a.size, x2.ctypes.data, y.ctypes.data,
+                                 x2.shape[0], x2.shape[1], x2.shape[1], _flags(exact, mfma)))
+    return y.reshape(x.shape)
+
+
+def lfilter_iir_device(b, a, x, out=None, xhist=None, yhist=None, exact: bool = False, mfma=None):
+    """dspx_lfilter_f64_dev on torch CUDA tensors: `b` (device taps), `a` (host coefficients), x/out
+    [nchan, n] or [n]; xhist / yhist: the samples / outputs that precede the call, oldest first."""
+    import torch
+
+    a = _np_f64(np.atleast_1d(a))
+    x2 = x.reshape(1, -1) if x.dim() == 1 else x
+    assert x2.is_cuda and x2.dtype == torch.float64 and x2.stride(1) == 1 and b.is_cuda and b.dtype == torch.float64
+    nchan, n = x2.shape
+    if out is None:
+        out = torch.empty_like(x)
+    o2 = out.reshape(1, -1) if out.dim() == 1 else out
+    assert o2.shape == x2.shape and o2.stride(1) == 1 and o2.dtype == torch.float64
+
+    def hist_args(h, width):
+        if h is None:
+            return None, 0
+        h2 = h.reshape(1, -1) if h.dim() == 1 else h
+        assert h2.is_cuda and h2.dtype == torch.float64 and h2.shape == (nchan, width) and h2.stride(1) == 1
+        return h2.data_ptr(), h2.stride(0)
+
+    xh, xhs = hist_args(xhist, max(b.numel() - 1, 0))
+    yh, yhs = hist_args(yhist, max(a.size - 1, 0))
+    need = int(lib().dspx_lfilter_workspace_bytes(a.size, nchan, n))
+    work = torch.empty(max(need, 1), dtype=torch.uint8, device=x.device)
+    check(lib().dspx_lfilter_f64_dev(b.data_ptr(), b.numel(), a.ctypes.data, a.size, x2.data_ptr(), x2.stride(0), xh, xhs,
+                                     yh, yhs, o2.data_ptr(), o2.stride(0), nchan, n, work.data_ptr(), need,
+                                     _flags(exact, mfma), _stream_ptr()))
+    return out
+
+
 def lfilter_stream(b, hist, x, exact: bool = False) -> np.ndarray:
     """One chunk of a stream: `hist` (ntaps-1 samples per channel, updated in place) carries the state."""
     b, x = _np_f64(b), _np_f64(x)

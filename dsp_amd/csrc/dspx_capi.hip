@@ -18,6 +18,7 @@
 #include "dspx.h"
 #include "dspx_common.h"
 #include "fir_kernels.h"
+#include "iir_kernels.h"
 
 namespace dspx {
 
@@ -83,6 +84,58 @@ int launch_dev(const double* d_taps, size_t ntaps, const double* d_x, size_t x_s
     return DSPX_OK;
 }
 
+// The recursive tail of lfilter (dsp.hpp:366-368) for `order` = na - 1 >= 1 coefficients a[1..order].
+struct Tail {
+    dspx::IirCoef coef{};
+    int order = 0;
+    bool exact = false, scan = false;
+};
+
+// Fills `t` from the denominators; a[0] is never read (dsp.hpp:366 starts at j = 1).
+int make_tail(const double* a, size_t na, unsigned flags, Tail& t) {
+    t = Tail{};
+    if (na <= 1) return DSPX_OK;
+    if (!a) return fail(DSPX_ERR_INVALID, "denominators is NULL");
+    if (na - 1 > (size_t)dspx::kIirMaxOrder)
+        return fail(DSPX_ERR_INVALID, "at most %d denominator coefficients are supported, got %zu",
+                    dspx::kIirMaxOrder + 1, na);
+    t.order = (int)(na - 1);
+    for (int j = 0; j < t.order; ++j) t.coef.a[j] = a[j + 1];
+    t.exact = (flags & DSPX_FIR_EXACT) != 0;
+    // a recurrence whose state grows without bound (or non-finite coefficients) leaves the block-parallel
+    // path without usable matrix powers: such filters run on the sequential kernel
+    t.scan = !t.exact && dspx::iir_tables_usable(t.coef.a, t.order);
+    return DSPX_OK;
+}
+
+size_t tail_workspace_bytes(const Tail& t, size_t nchan, size_t n) {
+    return t.order && t.scan ? dspx::iir_workspace_bytes(nchan, n, t.order) : 0;
+}
+
+// Applies the tail in place to d_y (which holds the FIR part).  d_state: per channel the `order` outputs
+// that precede y[0], oldest first (nullable).  d_work: tail_workspace_bytes() for the channels of one launch.
+int launch_tail(const Tail& t, double* d_y, size_t y_stride, const double* d_state, size_t state_stride, size_t nchan,
+                size_t n, void* d_work, hipStream_t stream) {
+    if (t.order == 0 || nchan == 0 || n == 0) return DSPX_OK;
+    const size_t tiles = (n + dspx::kIirTile - 1) / dspx::kIirTile;
+    if (tiles > kMaxGrid) return fail(DSPX_ERR_INVALID, "n too large for one launch: %zu", n);
+    const size_t chans_per_launch = t.scan ? std::max<size_t>(1, kMaxGrid / tiles) : kMaxGrid;
+    for (size_t c0 = 0; c0 < nchan; c0 += chans_per_launch) {
+        dspx::IirShape s{};
+        s.y_stride = y_stride;
+        s.state_stride = state_stride;
+        s.n = (long long)n;
+        s.tiles_per_chan = (unsigned)tiles;
+        s.nchan = (unsigned)std::min(chans_per_launch, nchan - c0);
+        const double* st = d_state ? d_state + c0 * state_stride : nullptr;
+        if (t.scan)  // launches on one stream run in order, so the workspace is reused from launch to launch
+            DSPX_HIP(dspx::launch_iir_scan(t.coef, t.order, d_y + c0 * y_stride, st, s, d_work, stream));
+        else
+            DSPX_HIP(dspx::launch_iir_sequential(t.coef, t.order, d_y + c0 * y_stride, st, s, t.exact, stream));
+    }
+    return DSPX_OK;
+}
+
 int check_common(const double* taps, size_t ntaps, const void* x, const void* y, size_t nchan, size_t n,
                  unsigned flags) {
     if (int rc = dspx::check_flags(flags)) return rc;
@@ -140,7 +193,9 @@ std::vector<std::vector<Piece>> make_plan(size_t nchan, size_t n, int G) {
 // the stream its copies and kernel run on, and the event that marks its result as back on the host.
 struct Slot {
     double *pin_in = nullptr, *pin_out = nullptr, *d_in = nullptr, *d_out = nullptr;
+    void* d_work = nullptr;          // workspace of the recursive tail
     size_t in_cap = 0, out_cap = 0;  // doubles
+    size_t work_cap = 0;             // bytes
     hipStream_t stream = nullptr;
     hipEvent_t done = nullptr;
 };
@@ -151,6 +206,7 @@ constexpr int kSlots = 8;
 // small filter).  One call uses an engine exclusively; concurrent calls on a device get engines of their own.
 struct Engine {
     int device = -1;
+    double* d_tail_state = nullptr;  // the last outputs of a piece, for the piece that continues its channel
     Slot slots[kSlots];
 };
 
@@ -170,7 +226,9 @@ void destroy_engine(Engine* e) {
         if (s.pin_out) (void)hipHostFree(s.pin_out);
         if (s.d_in) (void)hipFree(s.d_in);
         if (s.d_out) (void)hipFree(s.d_out);
+        if (s.d_work) (void)hipFree(s.d_work);
     }
+    if (e->d_tail_state) (void)hipFree(e->d_tail_state);
     (void)hipSetDevice(cur);
     delete e;
 }
@@ -193,6 +251,7 @@ int acquire_engine(int device, Engine** out) {
             DSPX_HIP(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
             DSPX_HIP(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
         }
+        DSPX_HIP(hipMalloc((void**)&e->d_tail_state, dspx::kIirMaxOrder * sizeof(double)));
         return DSPX_OK;
     };
     if (int rc = body()) {
@@ -218,7 +277,13 @@ void release_engine(Engine* e, bool healthy) {
     destroy_engine(e);
 }
 
-int grow_slot(Slot& s, size_t in_doubles, size_t out_doubles) {
+int grow_slot(Slot& s, size_t in_doubles, size_t out_doubles, size_t work_bytes) {
+    if (s.work_cap < work_bytes) {
+        if (s.d_work) DSPX_HIP(hipFree(s.d_work));
+        s.d_work = nullptr, s.work_cap = 0;
+        DSPX_HIP(hipMalloc(&s.d_work, work_bytes));
+        s.work_cap = work_bytes;
+    }
     if (s.in_cap < in_doubles) {
         if (s.pin_in) DSPX_HIP(hipHostFree(s.pin_in));
         if (s.d_in) DSPX_HIP(hipFree(s.d_in));
@@ -256,11 +321,17 @@ struct Pipeline {
     size_t ntaps, stride;
     unsigned flags;
     const std::vector<Piece>* pieces;
+    const Tail* tail;  // recursive part, order 0 for none
     std::mutex mu;
     std::condition_variable cv;
     std::vector<unsigned char> state;  // per piece: 0 waiting, 1 on the device, 2 delivered
     int rc = DSPX_OK;                  // first failure
     std::string msg;
+
+    Pipeline(int device_, Engine* eng_, const double* taps_, const double* hist0_, const double* x_, double* y_,
+             size_t ntaps_, size_t stride_, unsigned flags_, const std::vector<Piece>* pieces_, const Tail* tail_)
+        : device(device_), eng(eng_), taps(taps_), hist0(hist0_), x(x_), y(y_), ntaps(ntaps_), stride(stride_),
+          flags(flags_), pieces(pieces_), tail(tail_), state(pieces_->size(), 0) {}
 
     void set_error(int code) {
         std::lock_guard<std::mutex> lk(mu);
@@ -284,7 +355,9 @@ struct Pipeline {
         const Piece& p = (*pieces)[i];
         Slot& s = eng->slots[i % kSlots];
         const PieceGeom g(ntaps, p.len);
-        if (int grc = grow_slot(s, g.taps_pad + g.in_pitch * p.cnt, g.out_pitch * p.cnt)) return grc;
+        if (int grc = grow_slot(s, g.taps_pad + g.in_pitch * p.cnt, g.out_pitch * p.cnt,
+                                tail_workspace_bytes(*tail, p.cnt, p.len)))
+            return grc;
         if (ntaps) std::memcpy(s.pin_in, taps, ntaps * sizeof(double));
         // history: the lead samples that exist in the caller's buffer; before them the caller's
         // initial history (samples s0 .. hl-1 of it when lead == s0 < hl), or zeros
@@ -312,6 +385,22 @@ struct Pipeline {
                                  with_hist ? d_rows + (g.hl_pad - g.hl) : nullptr, g.in_pitch, s.d_out, g.out_pitch,
                                  p.cnt, p.len, flags, s.stream))
             return lrc;
+        if (tail->order) {
+            // a piece that continues a channel starts from the last outputs of the piece before it, which
+            // runs on another stream: wait for it (pieces of a channel are issued in order by one thread)
+            const double* d_state = nullptr;
+            if (p.s0 > 0) {
+                DSPX_HIP(hipStreamWaitEvent(s.stream, eng->slots[(i - 1) % kSlots].done, 0));
+                d_state = eng->d_tail_state;
+            }
+            if (int trc = launch_tail(*tail, s.d_out, g.out_pitch, d_state, (size_t)tail->order, p.cnt, p.len, s.d_work,
+                                      s.stream))
+                return trc;
+            const bool continues = i + 1 < pieces->size() && (*pieces)[i + 1].s0 > 0;
+            if (continues)  // cnt == 1 and len >= order here
+                DSPX_HIP(hipMemcpyAsync(eng->d_tail_state, s.d_out + (p.len - (size_t)tail->order),
+                                        (size_t)tail->order * sizeof(double), hipMemcpyDeviceToDevice, s.stream));
+        }
         DSPX_HIP(hipMemcpyAsync(s.pin_out, s.d_out, g.out_pitch * p.cnt * sizeof(double), hipMemcpyDeviceToHost,
                                 s.stream));
         DSPX_HIP(hipEventRecord(s.done, s.stream));
@@ -353,13 +442,13 @@ struct Pipeline {
 // thread; larger ones add threads (up to `max_threads` each way) so that the copies into and out of pinned
 // staging overlap the transfers and the kernels.
 int run_device(int device, const double* taps, size_t ntaps, const double* hist0, const double* x, double* y,
-               size_t stride, const std::vector<Piece>& pieces, unsigned flags, size_t max_threads) {
+               size_t stride, const std::vector<Piece>& pieces, unsigned flags, size_t max_threads,
+               const Tail& tail = Tail{}) {
     if (pieces.empty()) return DSPX_OK;
     DSPX_HIP(hipSetDevice(device));
     Engine* eng = nullptr;
     if (int rc = acquire_engine(device, &eng)) return rc;
-    Pipeline pl{device, eng, taps, hist0, x, y, ntaps, stride, flags, &pieces};
-    pl.state.assign(pieces.size(), 0);
+    Pipeline pl(device, eng, taps, hist0, x, y, ntaps, stride, flags, &pieces, &tail);
     auto body = [&]() -> int {
         if (pieces.size() <= 2) {
             for (size_t i = 0; i < pieces.size(); ++i)
@@ -370,7 +459,10 @@ int run_device(int device, const double* taps, size_t ntaps, const double* hist0
         }
         // copy threads per direction: measured on an MI355X host, 1 / 2 / 3 threads move 3.2 / 3.7 / 4.1 G
         // samples/s end to end; more than 3 gain little and take cores from the caller
-        const size_t nthreads = std::min<size_t>(max_threads, pieces.size() >= 32 ? 3 : pieces.size() >= 8 ? 2 : 1);
+        size_t nthreads = std::min<size_t>(max_threads, pieces.size() >= 32 ? 3 : pieces.size() >= 8 ? 2 : 1);
+        if (tail.order)  // pieces that continue a channel must be issued in order
+            for (const Piece& p : pieces)
+                if (p.s0 > 0) nthreads = 1;
         std::vector<std::thread> workers;
         for (size_t k = 0; k < nthreads; ++k) workers.emplace_back([&pl, k, nthreads] { pl.consumer(k, nthreads); });
         for (size_t k = 1; k < nthreads; ++k) workers.emplace_back([&pl, k, nthreads] { pl.producer(k, nthreads); });
@@ -390,7 +482,7 @@ int run_device(int device, const double* taps, size_t ntaps, const double* hist0
 }
 
 int host_path(const double* taps, size_t ntaps, const double* hist0, const double* x, double* y, size_t nchan,
-              size_t n, size_t stride, int ngpus, unsigned flags) {
+              size_t n, size_t stride, int ngpus, unsigned flags, const Tail& tail = Tail{}) {
     if (int rc = check_common(taps, ntaps, x, y, nchan, n, flags)) return rc;
     if (nchan == 0 || n == 0) return DSPX_OK;
     if (stride < n) return fail(DSPX_ERR_INVALID, "stride (%zu) < n (%zu)", stride, n);
@@ -403,7 +495,7 @@ int host_path(const double* taps, size_t ntaps, const double* hist0, const doubl
     if (ngpus < 0) {  // single-device entry points: stay on the caller's current device
         std::vector<Piece> pieces;
         cut_pieces(0, nchan, 0, n, pieces);
-        return run_device(cur, taps, ntaps, hist0, x, y, stride, pieces, flags, 3);
+        return run_device(cur, taps, ntaps, hist0, x, y, stride, pieces, flags, 3, tail);
     }
     const int G = ngpus == 0 ? ndev : ngpus;
     if (G > ndev) return fail(DSPX_ERR_INVALID, "ngpus (%d) exceeds visible devices (%d)", G, ndev);
@@ -522,6 +614,40 @@ int dspx_fir_f64_stream(const double* taps, size_t ntaps, double* hist, const do
         }
     }
     return DSPX_OK;
+}
+
+int dspx_lfilter_f64(const double* b, size_t nb, const double* a, size_t na, const double* x, double* y, size_t nchan,
+                     size_t n, size_t stride, unsigned flags) {
+    if (int rc = dspx::check_flags(flags)) return rc;
+    Tail tail;
+    if (int rc = make_tail(a, na, flags, tail)) return rc;
+    return host_path(b, nb, nullptr, x, y, nchan, n, stride, -1, flags, tail);
+}
+
+size_t dspx_lfilter_workspace_bytes(size_t na, size_t nchan, size_t n) {
+    if (na <= 1 || na - 1 > (size_t)dspx::kIirMaxOrder) return 0;
+    const size_t tiles = (n + dspx::kIirTile - 1) / dspx::kIirTile;
+    const size_t per_launch = std::min(nchan, std::max<size_t>(1, kMaxGrid / std::max<size_t>(tiles, 1)));
+    return dspx::iir_workspace_bytes(per_launch, n, (int)(na - 1));
+}
+
+int dspx_lfilter_f64_dev(const double* d_b, size_t nb, const double* a, size_t na, const double* d_x, size_t x_stride,
+                         const double* d_xhist, size_t xhist_stride, const double* d_yhist, size_t yhist_stride,
+                         double* d_y, size_t y_stride, size_t nchan, size_t n, void* d_work, size_t work_bytes,
+                         unsigned flags, void* stream) {
+    Tail tail;
+    if (int rc = dspx::check_flags(flags)) return rc;
+    if (int rc = make_tail(a, na, flags, tail)) return rc;
+    if (int rc = dspx_fir_f64_dev(d_b, nb, d_x, x_stride, d_xhist, xhist_stride, d_y, y_stride, nchan, n, flags, stream))
+        return rc;
+    if (tail.order == 0 || nchan == 0 || n == 0) return DSPX_OK;
+    if (d_yhist && nchan > 1 && yhist_stride < (size_t)tail.order)
+        return fail(DSPX_ERR_INVALID, "yhist_stride (%zu) < na-1", yhist_stride);
+    const size_t need = tail.scan ? dspx_lfilter_workspace_bytes(na, nchan, n) : 0;
+    if (need && (!d_work || work_bytes < need))
+        return fail(DSPX_ERR_INVALID, "workspace of %zu bytes needed (dspx_lfilter_workspace_bytes), got %zu", need,
+                    d_work ? work_bytes : (size_t)0);
+    return launch_tail(tail, d_y, y_stride, d_yhist, yhist_stride, nchan, n, d_work, static_cast<hipStream_t>(stream));
 }
 
 long dspx_fir_plan(size_t nchan, size_t n, int ngpus, dspx_piece* out, size_t cap) {

@@ -1,0 +1,60 @@
+// Internal launch interface of the recursive tail of dsp::lfilter (dsp.hpp:366-368):
+//   y[i] = w[i] - sum_{j=1..P} a[j] * y[i-j],   P = na - 1,
+// applied in place to a buffer that holds w (the output of the FIR part).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+
+namespace dspx {
+
+constexpr int kIirMaxOrder = 8;   // P of the kernels below (na <= 9)
+constexpr int kIirLevels = 8;     // log2 of the 256 lanes (or tiles) one scan covers
+constexpr int kIirTile = 2048;    // samples per workgroup: 256 lanes x 8 consecutive samples
+
+// Coefficients by value (kernel argument): a[j-1] = a_j.
+struct IirCoef {
+    double a[kIirMaxOrder];
+};
+
+// Powers of the companion matrix A of the recurrence (state = the P most recent outputs, newest first):
+// lane[d] = (A^8)^(2^d) carries a state across 2^d lanes, tile[d] = (A^2048)^(2^d) across 2^d tiles.
+// Each entry is an unevaluated sum hi + lo of two doubles: a state of a narrow-band filter is a smooth
+// sequence, and a matrix power applied to it cancels terms thousands of times larger than the result, so
+// the entries and the dot products carry about twice the precision of a double.
+struct IirMatrix {
+    double hi[kIirMaxOrder][kIirMaxOrder];
+    double lo[kIirMaxOrder][kIirMaxOrder];
+};
+struct IirTables {
+    IirMatrix lane[kIirLevels];
+    IirMatrix tile[kIirLevels];
+};
+
+struct IirShape {
+    unsigned long long y_stride;      // elements between channels of y
+    unsigned long long state_stride;  // elements between channels of the incoming state
+    long long n;                      // samples per channel
+    unsigned tiles_per_chan;          // ceil(n / kIirTile)
+    unsigned nchan;
+};
+
+// Bytes of device workspace the scan path needs for `nchan` channels of `n` samples (tables + one
+// state per tile).
+size_t iir_workspace_bytes(size_t nchan, size_t n, int order);
+
+// True when every entry of the matrix powers stays far below overflow, i.e. the scan path can be used;
+// otherwise (a recurrence that grows without bound) only the sequential kernel is meaningful.
+bool iir_tables_usable(const double* a, int order);
+
+// Block-parallel path (fused multiply-adds; rounding differs from the sequential loop).  `work` holds
+// iir_workspace_bytes(); `state_in` (nullable) holds per channel the P outputs that precede y[0], oldest first.
+hipError_t launch_iir_scan(const IirCoef& coef, int order, double* y, const double* state_in, const IirShape& shape,
+                           void* work, hipStream_t stream);
+
+// One lane per channel, samples in order.  exact: product and subtraction rounded separately, j ascending,
+// bit-identical to dsp.hpp:366-368; otherwise one fused multiply-add per coefficient.
+hipError_t launch_iir_sequential(const IirCoef& coef, int order, double* y, const double* state_in,
+                                 const IirShape& shape, bool exact, hipStream_t stream);
+
+}  // namespace dspx

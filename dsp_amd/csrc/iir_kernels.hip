@@ -1,0 +1,409 @@
+// gfx950 kernels for the recursive tail of dsp::lfilter (dsp.hpp:366-368), in place on a buffer
+// that holds the FIR part w:   y[i] = w[i] - sum_{j=1..P} a[j] * y[i-j].
+//
+// Block-parallel path.  The recurrence is linear, so the state (the P most recent outputs) after a run
+// of L samples is  A^L * (state before) + (state the run reaches from zero).  A lane owns 8 consecutive
+// samples, a workgroup a tile of 2048:
+//   1. iir_tile_state_kernel: every lane runs its 8 samples from zero state; a Kogge-Stone scan over the
+//      256 lanes with the constant matrices (A^8)^(2^d) gives the state the tile reaches from zero.
+//   2. iir_tile_scan_kernel: one workgroup per channel scans those tile states with (A^2048)^(2^d), 256 tiles
+//      per pass, and leaves in their place the state every tile starts from.
+//   3. iir_apply_kernel: as 1., with the tile's true starting state folded into lane 0; every lane then knows
+//      the state it starts from and runs its 8 samples again from it, which yields the outputs.
+// HBM traffic: w is read twice and y written once (24 bytes per sample).
+//
+// Sequential path (iir_seq_kernel): one lane per channel, samples in order, staged through LDS in 64x64
+// blocks so that global accesses stay coalesced; with EXACT it is bit-identical to the reference loop.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+
+#include "iir_kernels.h"
+
+namespace dspx {
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kR = kIirTile / kBlock;  // samples per lane
+static_assert(kR == 8 && (1 << kIirLevels) == kBlock, "scan geometry");
+constexpr int kImg = kIirTile + 2 * (kIirTile / 8);  // tile image: sample q at q + 2*(q/8) (lane stride 80 bytes)
+
+template <bool EXACT> __device__ __forceinline__ double tail_step(double a, double yp, double acc) {
+    if constexpr (EXACT)
+        return __dsub_rn(acc, __dmul_rn(a, yp));
+    else
+        return __builtin_fma(-a, yp, acc);
+}
+
+// One step of the recurrence for a lane: st[0] is the most recent output.
+template <int P> __device__ __forceinline__ double advance(double (&st)[P], const IirCoef& coef, double w) {
+    double acc = w;
+#pragma unroll
+    for (int j = 0; j < P; ++j) acc = __builtin_fma(-coef.a[j], st[j], acc);
+#pragma unroll
+    for (int k = P - 1; k > 0; --k) st[k] = st[k - 1];
+    st[0] = acc;
+    return acc;
+}
+
+// Double-double helpers (the library is built with -ffp-contract=off and without fast-math, so every
+// operation below is the IEEE operation written).
+struct dd {
+    double hi, lo;
+};
+__device__ __forceinline__ dd two_sum(double a, double b) {
+    const double s = a + b, bb = s - a;
+    return {s, (a - (s - bb)) + (b - bb)};
+}
+__device__ __forceinline__ dd quick_two_sum(double a, double b) {  // |a| >= |b|
+    const double s = a + b;
+    return {s, b - (s - a)};
+}
+__device__ __forceinline__ dd dd_add(dd a, dd b) {
+    dd s = two_sum(a.hi, b.hi);
+    s.lo += a.lo + b.lo;
+    return quick_two_sum(s.hi, s.lo);
+}
+__device__ __forceinline__ dd dd_mul_d(dd a, double b) {
+    const double p = a.hi * b;
+    double e = __builtin_fma(a.hi, b, -p);
+    e = __builtin_fma(a.lo, b, e);
+    return quick_two_sum(p, e);
+}
+__device__ __forceinline__ dd dd_mul(dd a, dd b) {
+    const double p = a.hi * b.hi;
+    double e = __builtin_fma(a.hi, b.hi, -p);
+    e = __builtin_fma(a.hi, b.lo, e);
+    e = __builtin_fma(a.lo, b.hi, e);
+    return quick_two_sum(p, e);
+}
+
+// s <- s + M * p, accumulated in double-double, rounded to double once per component
+template <int P>
+__device__ __forceinline__ void add_matvec(double (&s)[P], const IirMatrix& M, const double (&p)[P]) {
+#pragma unroll
+    for (int r = 0; r < P; ++r) {
+        dd acc{s[r], 0.0};
+#pragma unroll
+        for (int c = 0; c < P; ++c) acc = dd_add(acc, dd_mul_d(dd{M.hi[r][c], M.lo[r][c]}, p[c]));
+        s[r] = acc.hi;
+    }
+}
+
+// Inclusive scan over the 256 lanes of a workgroup: s_k <- sum_{i <= k} M0^(k-i) s_i, with M[d] = M0^(2^d).
+// buf: 2 * P * kBlock doubles of LDS (component-major, so lanes hit consecutive banks).
+template <int P>
+__device__ __forceinline__ void scan_states(double (&s)[P], const IirMatrix* M, double* buf, int tid) {
+    int cur = 0;
+    for (int d = 0; d < kIirLevels; ++d) {
+        double* b = buf + cur * P * kBlock;
+#pragma unroll
+        for (int k = 0; k < P; ++k) b[k * kBlock + tid] = s[k];
+        __syncthreads();
+        const int from = tid - (1 << d);
+        if (from >= 0) {
+            double p[P];
+#pragma unroll
+            for (int k = 0; k < P; ++k) p[k] = b[k * kBlock + from];
+            add_matvec<P>(s, M[d], p);
+        }
+        cur ^= 1;  // the next level writes the other half: nobody can still be reading it (one barrier between)
+    }
+}
+
+// Loads the tile into the LDS image (zeros past the end of the channel) and returns the lane's 8 samples.
+__device__ __forceinline__ void load_tile(const double* __restrict__ yt, long long left, double* img, int tid,
+                                          double (&w)[kR]) {
+#pragma unroll
+    for (int i = 0; i < kR; ++i) {
+        const int q = tid + i * kBlock;
+        img[q + 2 * (q >> 3)] = q < left ? yt[q] : 0.0;
+    }
+    __syncthreads();
+    const double2* mine = reinterpret_cast<const double2*>(img + 10 * tid);
+#pragma unroll
+    for (int i = 0; i < kR / 2; ++i) {
+        const double2 v = mine[i];
+        w[2 * i] = v.x, w[2 * i + 1] = v.y;
+    }
+}
+
+__device__ __forceinline__ void locate(const IirShape& s, unsigned& chan, unsigned& tile) {
+    chan = blockIdx.x / s.tiles_per_chan;
+    tile = blockIdx.x - chan * s.tiles_per_chan;
+}
+
+// Computes (A^8)^(2^d) and (A^2048)^(2^d) by repeated squaring in double-double; one workgroup of 64
+// threads, thread = element.
+__global__ __launch_bounds__(64) void iir_tables_kernel(IirCoef coef, int order, IirTables* out) {
+    __shared__ double mh[kIirMaxOrder][kIirMaxOrder], ml[kIirMaxOrder][kIirMaxOrder];
+    const int r = threadIdx.x / kIirMaxOrder, c = threadIdx.x % kIirMaxOrder;
+    // companion matrix, padded with zeros beyond `order`
+    double v = 0.0;
+    if (r < order && c < order) v = r == 0 ? -coef.a[c] : (c == r - 1 ? 1.0 : 0.0);
+    mh[r][c] = v, ml[r][c] = 0.0;
+    __syncthreads();
+    auto square = [&]() {
+        dd acc{0.0, 0.0};
+        for (int k = 0; k < kIirMaxOrder; ++k) acc = dd_add(acc, dd_mul(dd{mh[r][k], ml[r][k]}, dd{mh[k][c], ml[k][c]}));
+        __syncthreads();
+        mh[r][c] = acc.hi, ml[r][c] = acc.lo;
+        __syncthreads();
+        return acc;
+    };
+    dd e{v, 0.0};
+    for (int i = 0; i < 3; ++i) e = square();  // A^8
+    for (int d = 0; d < kIirLevels; ++d) {
+        out->lane[d].hi[r][c] = e.hi, out->lane[d].lo[r][c] = e.lo;
+        e = square();
+    }
+    // e = (A^8)^256 = A^2048
+    for (int d = 0; d < kIirLevels; ++d) {
+        out->tile[d].hi[r][c] = e.hi, out->tile[d].lo[r][c] = e.lo;
+        if (d + 1 < kIirLevels) e = square();
+    }
+}
+
+template <int P>
+__global__ __launch_bounds__(kBlock) void iir_tile_state_kernel(IirCoef coef, const double* __restrict__ y,
+                                                                const IirTables* __restrict__ tables,
+                                                                double* __restrict__ states, IirShape s) {
+    __shared__ __align__(16) double img[kImg];
+    __shared__ double buf[2 * P * kBlock];
+    const int tid = threadIdx.x;
+    unsigned chan, tile;
+    locate(s, chan, tile);
+    const long long start = (long long)tile * kIirTile;
+    double w[kR];
+    load_tile(y + (unsigned long long)chan * s.y_stride + start, s.n - start, img, tid, w);
+    double st[P];
+#pragma unroll
+    for (int k = 0; k < P; ++k) st[k] = 0.0;
+#pragma unroll
+    for (int t = 0; t < kR; ++t) advance<P>(st, coef, w[t]);
+    scan_states<P>(st, tables->lane, buf, tid);
+    if (tid == kBlock - 1) {
+        double* dst = states + ((unsigned long long)chan * s.tiles_per_chan + tile) * P;
+#pragma unroll
+        for (int k = 0; k < P; ++k) dst[k] = st[k];
+    }
+}
+
+// One workgroup per channel.  On entry states[chan][t] is the state tile t reaches from zero; on exit it is
+// the state tile t starts from.
+template <int P>
+__global__ __launch_bounds__(kBlock) void iir_tile_scan_kernel(const IirTables* __restrict__ tables,
+                                                               double* __restrict__ states,
+                                                               const double* __restrict__ state_in, IirShape s) {
+    __shared__ double buf[2 * P * kBlock];
+    __shared__ double last[P];
+    const int tid = threadIdx.x;
+    const unsigned chan = blockIdx.x;
+    double* mine = states + (unsigned long long)chan * s.tiles_per_chan * P;
+    double carry[P];
+#pragma unroll
+    for (int k = 0; k < P; ++k)  // state_in is oldest first
+        carry[k] = state_in ? state_in[(unsigned long long)chan * s.state_stride + (P - 1 - k)] : 0.0;
+    for (unsigned base = 0; base < s.tiles_per_chan; base += kBlock) {
+        const unsigned t = base + tid;
+        double st[P];
+#pragma unroll
+        for (int k = 0; k < P; ++k) st[k] = t < s.tiles_per_chan ? mine[(unsigned long long)t * P + k] : 0.0;
+        if (tid == 0) add_matvec<P>(st, tables->tile[0], carry);  // what the first tile of this pass ends in
+        scan_states<P>(st, tables->tile, buf, tid);
+        // the state a tile starts from is what the tile before it ends in
+        double* b = buf;  // free: the scan's last level wrote the other half, and a barrier follows below
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < P; ++k) b[k * kBlock + tid] = st[k];
+        if (tid == kBlock - 1) {
+#pragma unroll
+            for (int k = 0; k < P; ++k) last[k] = st[k];
+        }
+        __syncthreads();
+        if (t < s.tiles_per_chan) {
+#pragma unroll
+            for (int k = 0; k < P; ++k) mine[(unsigned long long)t * P + k] = tid == 0 ? carry[k] : b[k * kBlock + tid - 1];
+        }
+#pragma unroll
+        for (int k = 0; k < P; ++k) carry[k] = last[k];
+        __syncthreads();
+    }
+}
+
+template <int P>
+__global__ __launch_bounds__(kBlock) void iir_apply_kernel(IirCoef coef, double* __restrict__ y,
+                                                           const IirTables* __restrict__ tables,
+                                                           const double* __restrict__ states, IirShape s) {
+    __shared__ __align__(16) double img[kImg];
+    __shared__ double buf[2 * P * kBlock];
+    const int tid = threadIdx.x;
+    unsigned chan, tile;
+    locate(s, chan, tile);
+    const long long start = (long long)tile * kIirTile;
+    const long long left = s.n - start;
+    double* __restrict__ yt = y + (unsigned long long)chan * s.y_stride + start;
+    double w[kR];
+    load_tile(yt, left, img, tid, w);
+    double st[P], in[P];
+#pragma unroll
+    for (int k = 0; k < P; ++k) st[k] = 0.0;
+#pragma unroll
+    for (int t = 0; t < kR; ++t) advance<P>(st, coef, w[t]);
+    const double* src = states + ((unsigned long long)chan * s.tiles_per_chan + tile) * P;
+#pragma unroll
+    for (int k = 0; k < P; ++k) in[k] = src[k];  // the state the tile starts from
+    if (tid == 0) add_matvec<P>(st, tables->lane[0], in);
+    scan_states<P>(st, tables->lane, buf, tid);
+    // a lane starts from what the lane before it ends in
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < P; ++k) buf[k * kBlock + tid] = st[k];
+    __syncthreads();
+    if (tid > 0) {
+#pragma unroll
+        for (int k = 0; k < P; ++k) in[k] = buf[k * kBlock + tid - 1];
+    }
+    double2* mine = reinterpret_cast<double2*>(img + 10 * tid);
+#pragma unroll
+    for (int i = 0; i < kR / 2; ++i) {
+        const double a = advance<P>(in, coef, w[2 * i]);
+        const double b = advance<P>(in, coef, w[2 * i + 1]);
+        mine[i] = make_double2(a, b);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < kR; ++i) {
+        const int q = tid + i * kBlock;
+        if (q < left) yt[q] = img[q + 2 * (q >> 3)];
+    }
+}
+
+// 64 channels per workgroup (one wave), one lane per channel, 64 samples per pass through LDS.
+constexpr int kSeqChans = 64, kSeqSamples = 64;
+template <int P, bool EXACT>
+__global__ __launch_bounds__(kSeqChans) void iir_seq_kernel(IirCoef coef, double* __restrict__ y,
+                                                            const double* __restrict__ state_in, IirShape s) {
+    __shared__ double blk[kSeqChans][kSeqSamples + 1];
+    const int lane = threadIdx.x;
+    const unsigned long long c0 = (unsigned long long)blockIdx.x * kSeqChans;
+    const int rows = (int)min((unsigned long long)kSeqChans, s.nchan - c0);
+    const bool have = lane < rows;
+    double st[P];
+    long long known = 0;  // how many outputs before the current sample exist (the reference skips the others)
+#pragma unroll
+    for (int k = 0; k < P; ++k) st[k] = 0.0;
+    if (state_in && have) {
+#pragma unroll
+        for (int k = 0; k < P; ++k) st[k] = state_in[(c0 + lane) * s.state_stride + (P - 1 - k)];
+        known = P;
+    }
+    for (long long i0 = 0; i0 < s.n; i0 += kSeqSamples) {
+        const int cols = (int)min((long long)kSeqSamples, s.n - i0);
+        for (int r = 0; r < rows; ++r)
+            if (lane < cols) blk[r][lane] = y[(c0 + r) * s.y_stride + i0 + lane];
+        __syncthreads();
+        if (have) {
+            for (int t = 0; t < cols; ++t) {
+                double acc = blk[lane][t];
+#pragma unroll
+                for (int j = 0; j < P; ++j)
+                    if (j < known) acc = tail_step<EXACT>(coef.a[j], st[j], acc);
+#pragma unroll
+                for (int k = P - 1; k > 0; --k) st[k] = st[k - 1];
+                st[0] = acc;
+                known = min(known + 1, (long long)P);
+                blk[lane][t] = acc;
+            }
+        }
+        __syncthreads();
+        for (int r = 0; r < rows; ++r)
+            if (lane < cols) y[(c0 + r) * s.y_stride + i0 + lane] = blk[r][lane];
+        __syncthreads();
+    }
+}
+
+template <int P>
+hipError_t scan_path(const IirCoef& coef, double* y, const double* state_in, const IirShape& s, IirTables* tables,
+                     double* states, hipStream_t stream) {
+    const unsigned total = s.nchan * s.tiles_per_chan;
+    hipLaunchKernelGGL(iir_tables_kernel, dim3(1), dim3(64), 0, stream, coef, P, tables);
+    hipLaunchKernelGGL(iir_tile_state_kernel<P>, dim3(total), dim3(kBlock), 0, stream, coef, y, tables, states, s);
+    hipLaunchKernelGGL(iir_tile_scan_kernel<P>, dim3(s.nchan), dim3(kBlock), 0, stream, tables, states, state_in, s);
+    hipLaunchKernelGGL(iir_apply_kernel<P>, dim3(total), dim3(kBlock), 0, stream, coef, y, tables, states, s);
+    return hipGetLastError();
+}
+
+template <int P>
+hipError_t seq_path(const IirCoef& coef, double* y, const double* state_in, const IirShape& s, bool exact,
+                    hipStream_t stream) {
+    const unsigned groups = (s.nchan + kSeqChans - 1) / kSeqChans;
+    if (exact)
+        hipLaunchKernelGGL((iir_seq_kernel<P, true>), dim3(groups), dim3(kSeqChans), 0, stream, coef, y, state_in, s);
+    else
+        hipLaunchKernelGGL((iir_seq_kernel<P, false>), dim3(groups), dim3(kSeqChans), 0, stream, coef, y, state_in, s);
+    return hipGetLastError();
+}
+
+constexpr size_t kTablesBytes = (sizeof(IirTables) + 255) & ~size_t(255);
+
+}  // namespace
+
+size_t iir_workspace_bytes(size_t nchan, size_t n, int order) {
+    const size_t tiles = (n + kIirTile - 1) / kIirTile;
+    return kTablesBytes + nchan * tiles * (size_t)order * sizeof(double);
+}
+
+bool iir_tables_usable(const double* a, int order) {
+    // the same squarings as iir_tables_kernel; every entry must stay far from overflow
+    double m[kIirMaxOrder][kIirMaxOrder] = {}, t[kIirMaxOrder][kIirMaxOrder];
+    for (int r = 0; r < order; ++r)
+        for (int c = 0; c < order; ++c) m[r][c] = r == 0 ? -a[c] : (c == r - 1 ? 1.0 : 0.0);
+    for (int step = 0; step < 3 + 2 * kIirLevels - 1; ++step) {
+        for (int r = 0; r < order; ++r)
+            for (int c = 0; c < order; ++c) {
+                double acc = 0.0;
+                for (int k = 0; k < order; ++k) acc += m[r][k] * m[k][c];
+                t[r][c] = acc;
+            }
+        for (int r = 0; r < order; ++r)
+            for (int c = 0; c < order; ++c) {
+                if (!(std::fabs(t[r][c]) < 1e150)) return false;  // also false for NaN
+                m[r][c] = t[r][c];
+            }
+    }
+    return true;
+}
+
+#define DSPX_IIR_DISPATCH(call)       \
+    switch (order) {                  \
+    case 1: return call(1);           \
+    case 2: return call(2);           \
+    case 3: return call(3);           \
+    case 4: return call(4);           \
+    case 5: return call(5);           \
+    case 6: return call(6);           \
+    case 7: return call(7);           \
+    case 8: return call(8);           \
+    default: return hipErrorInvalidValue; \
+    }
+
+hipError_t launch_iir_scan(const IirCoef& coef, int order, double* y, const double* state_in, const IirShape& shape,
+                           void* work, hipStream_t stream) {
+    if (shape.nchan == 0 || shape.n == 0) return hipSuccess;
+    IirTables* tables = static_cast<IirTables*>(work);
+    double* states = reinterpret_cast<double*>(static_cast<char*>(work) + kTablesBytes);
+#define DSPX_IIR_SCAN(P) scan_path<P>(coef, y, state_in, shape, tables, states, stream)
+    DSPX_IIR_DISPATCH(DSPX_IIR_SCAN)
+#undef DSPX_IIR_SCAN
+}
+
+hipError_t launch_iir_sequential(const IirCoef& coef, int order, double* y, const double* state_in,
+                                 const IirShape& shape, bool exact, hipStream_t stream) {
+    if (shape.nchan == 0 || shape.n == 0) return hipSuccess;
+#define DSPX_IIR_SEQ(P) seq_path<P>(coef, y, state_in, shape, exact, stream)
+    DSPX_IIR_DISPATCH(DSPX_IIR_SEQ)
+#undef DSPX_IIR_SEQ
+}
+
+}  // namespace dspx

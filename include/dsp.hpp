@@ -13,11 +13,13 @@
 // Tap design runs on the host and performs the same IEEE-754 operations in the same
 // order as the reference, so the taps are bit-identical.  lfilter hands contiguous
 // double buffers to the C ABI in dspx.h (libdspx.so, hand-written gfx950 kernels).
+// A denominator with more than one coefficient adds the recursive tail of the
+// reference loop (dsp.hpp:366-368) on the GPU as well.
 // There is no CPU filtering path in this header: a failing GPU call throws
 // std::runtime_error, and inputs the GPU path does not cover are rejected
 //   - at compile time when T or a container's value_type is not double,
-//   - with std::invalid_argument when the denominator has more than one
-//     coefficient (an IIR recurrence; reference dsp.hpp:366-368).
+//   - with std::invalid_argument when the denominator has more than nine
+//     coefficients.
 //
 // Requires C++20.  Link with -ldspx.
 #pragma once
@@ -219,14 +221,20 @@ void lfilter(lfilter_ctx_t<T>& ctx, const Container_1& numerators, const Contain
                     std::is_same_v<typename Container_2::value_type, double> &&
                     std::is_same_v<typename Container_3::value_type, double>,
                   "dsp::lfilter (MI355X): only T = double over containers of double is implemented");
-    if (denominators.size() > 1)
-        throw std::invalid_argument("dsp::lfilter (MI355X): denominators.size() > 1 (IIR) is not implemented");
     const std::size_t n = x.size();
     if (ctx.result.size() != n) [[unlikely]] ctx.result.resize(n);
     if (n == 0) return;
     const detail::double_view<Container_1> b(numerators);
     const detail::double_view<Container_3> in(x);
-    const int rc = dspx_fir_f64(b.data(), b.size(), in.data(), ctx.result.data(), n, DSPX_FIR_FMA);
+    int rc;
+    if (denominators.size() > 1) {  // the recursive tail, dsp.hpp:366-368
+        const detail::double_view<Container_2> a(denominators);
+        rc = dspx_lfilter_f64(b.data(), b.size(), a.data(), a.size(), in.data(), ctx.result.data(), 1, n, n,
+                              DSPX_FIR_FMA);
+        if (rc == DSPX_ERR_INVALID) throw std::invalid_argument(std::string("dsp::lfilter (MI355X): ") + dspx_last_error());
+    } else {
+        rc = dspx_fir_f64(b.data(), b.size(), in.data(), ctx.result.data(), n, DSPX_FIR_FMA);
+    }
     if (rc != DSPX_OK)
         throw std::runtime_error(std::string("dsp::lfilter (MI355X): ") + dspx_status_string(rc) + ": " +
                                  dspx_last_error());

@@ -100,6 +100,30 @@ DSPX_API int dspx_fir_f64_multi(const double* taps, size_t ntaps, const double* 
 DSPX_API int dspx_fir_f64_stream(const double* taps, size_t ntaps, double* hist, const double* x, double* y,
                                  size_t nchan, size_t n, size_t stride, unsigned flags);
 
+/* dsp::lfilter with a recursive part (dsp.hpp:342-371 including the tail 366-368):
+ *     y[i] = sum_{j < min(nb, i+1)} b[j] * x[i-j]  -  sum_{1 <= j < min(na, i+1)} a[j] * y[i-j]
+ * per channel, zero initial state; a[0] is never read (the reference does not normalise by it).  Host
+ * pointers, current device, layout as dspx_fir_f64_batched.  na <= 1 is the plain FIR; na may be at most 9.
+ * DSPX_FIR_EXACT: the tail runs one lane per channel in sample order with separately rounded products and
+ * subtractions, bit-identical to the reference (slow for few channels: the loop is sequential by nature).
+ * Default: block-parallel evaluation (per-lane runs joined by a scan over powers of the recurrence's
+ * companion matrix) with fused multiply-adds; its rounding differs from the sequential loop's, so parity is
+ * to tolerance, and it presumes a filter whose response does not grow without bound -- filters whose matrix
+ * powers overflow run on the sequential kernel instead. */
+DSPX_API int dspx_lfilter_f64(const double* b, size_t nb, const double* a, size_t na, const double* x, double* y,
+                              size_t nchan, size_t n, size_t stride, unsigned flags);
+
+/* Device-resident form: dspx_fir_f64_dev followed by the recursive tail, in place on d_y.  `a` is a HOST
+ * pointer (na coefficients, read during the call).  d_xhist as d_hist of dspx_fir_f64_dev; d_yhist (optional):
+ * per channel the na-1 outputs that precede y[0], oldest first (channel c at d_yhist + c*yhist_stride).
+ * d_work: device scratch of dspx_lfilter_workspace_bytes(na, nchan, n) bytes, 256-byte aligned, needed by the
+ * default (block-parallel) tail; it may be reused by later calls on the same stream. */
+DSPX_API size_t dspx_lfilter_workspace_bytes(size_t na, size_t nchan, size_t n);
+DSPX_API int dspx_lfilter_f64_dev(const double* d_b, size_t nb, const double* a, size_t na, const double* d_x,
+                                  size_t x_stride, const double* d_xhist, size_t xhist_stride, const double* d_yhist,
+                                  size_t yhist_stride, double* d_y, size_t y_stride, size_t nchan, size_t n,
+                                  void* d_work, size_t work_bytes, unsigned flags, void* stream);
+
 /* The sharding plan dspx_fir_f64_multi executes, exposed so that it can be inspected and
  * tested without GPUs: piece i covers channels [chan, chan + nchan) x samples
  * [start, start + len) and is assigned to `device`; the pieces of one device are staged

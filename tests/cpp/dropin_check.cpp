@@ -162,8 +162,31 @@ int main(int argc, char** argv) {
             }
             CHECK(worst <= 1e-12 * peak);
         }
-        // IIR denominators are outside the GPU path: loud error, no silent CPU fallback
-        CHECK(throws<std::invalid_argument>([&] { lfilter<double>(w, std::vector<double>{1.0, -0.5}, x); }));
+        // a denominator with a recursive part (reference dsp.hpp:366-368) runs on the GPU too; checked here
+        // against the loop written out (den[0] is not read, nothing is normalised by it)
+        {
+            const std::vector<double> num = {0.2, 0.3, 0.1}, den = {7.0, -1.1, 0.5, -0.05};
+            const auto got = lfilter<double>(num, den, x);
+            std::vector<double> want(x.size());
+            double peak = 0.0, worst = 0.0;
+            for (size_t i = 0; i < x.size(); ++i) {
+                double sum = 0.0;
+                for (size_t j = 0; j < std::min(num.size(), i + 1); ++j) sum += num[j] * x[i - j];
+                for (size_t j = 1; j < std::min(den.size(), i + 1); ++j) sum -= den[j] * want[i - j];
+                want[i] = sum;
+            }
+            CHECK(got.size() == x.size());
+            for (size_t i = 0; i < x.size(); ++i) {
+                peak = std::max(peak, std::abs(want[i]));
+                worst = std::max(worst, std::abs(want[i] - got[i]));
+            }
+            CHECK(worst <= 1e-12 * peak);
+            lfilter_ctx_t<double> rctx;
+            lfilter(rctx, num, den, x);
+            CHECK(rctx.result == got);
+            // more than nine denominator coefficients: loud error, no silent CPU path
+            CHECK(throws<std::invalid_argument>([&] { lfilter<double>(num, std::vector<double>(10, 0.01), x); }));
+        }
         // wavelet bank: error classes of the reference (dsp.hpp:1047-1119, 1153-1155, 1195-1197)
         auto [psi, grid] = integrate_wavelet<double>(cwt_wavelet_t::MORLET, 10);
         CHECK(throws<std::runtime_error>([&] { cwt<double>(x, std::vector<double>{0.0625}, psi, grid); }));   // too small
