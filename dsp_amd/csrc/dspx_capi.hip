@@ -127,6 +127,7 @@ int launch_tail(const Tail& t, double* d_y, size_t y_stride, const double* d_sta
         s.n = (long long)n;
         s.tiles_per_chan = (unsigned)tiles;
         s.nchan = (unsigned)std::min(chans_per_launch, nchan - c0);
+        s.vec2 = aligned16(d_y) && y_stride % 2 == 0;
         const double* st = d_state ? d_state + c0 * state_stride : nullptr;
         if (t.scan)  // launches on one stream run in order, so the workspace is reused from launch to launch
             DSPX_HIP(dspx::launch_iir_scan(t.coef, t.order, d_y + c0 * y_stride, st, s, d_work, stream));

@@ -10,7 +10,7 @@ namespace dspx {
 
 constexpr int kIirMaxOrder = 8;   // P of the kernels below (na <= 9)
 constexpr int kIirLevels = 8;     // log2 of the 256 lanes (or tiles) one scan covers
-constexpr int kIirTile = 2048;    // samples per workgroup: 256 lanes x 8 consecutive samples
+constexpr int kIirTile = 4096;    // samples per workgroup: 256 lanes x 16 consecutive samples
 
 // Coefficients by value (kernel argument): a[j-1] = a_j.
 struct IirCoef {
@@ -18,7 +18,7 @@ struct IirCoef {
 };
 
 // Powers of the companion matrix A of the recurrence (state = the P most recent outputs, newest first):
-// lane[d] = (A^8)^(2^d) carries a state across 2^d lanes, tile[d] = (A^2048)^(2^d) across 2^d tiles.
+// lane[d] = (A^16)^(2^d) carries a state across 2^d lanes, tile[d] = (A^4096)^(2^d) across 2^d tiles.
 // Each entry is an unevaluated sum hi + lo of two doubles: a state of a narrow-band filter is a smooth
 // sequence, and a matrix power applied to it cancels terms thousands of times larger than the result, so
 // the entries and the dot products carry about twice the precision of a double.
@@ -37,6 +37,7 @@ struct IirShape {
     long long n;                      // samples per channel
     unsigned tiles_per_chan;          // ceil(n / kIirTile)
     unsigned nchan;
+    int vec2;                         // y is 16-byte aligned and y_stride is even: 16-byte global accesses
 };
 
 // Bytes of device workspace the scan path needs for `nchan` channels of `n` samples (tables + one

@@ -2,14 +2,14 @@
 // that holds the FIR part w:   y[i] = w[i] - sum_{j=1..P} a[j] * y[i-j].
 //
 // Block-parallel path.  The recurrence is linear, so the state (the P most recent outputs) after a run
-// of L samples is  A^L * (state before) + (state the run reaches from zero).  A lane owns 8 consecutive
-// samples, a workgroup a tile of 2048:
-//   1. iir_tile_state_kernel: every lane runs its 8 samples from zero state; a Kogge-Stone scan over the
-//      256 lanes with the constant matrices (A^8)^(2^d) gives the state the tile reaches from zero.
-//   2. iir_tile_scan_kernel: one workgroup per channel scans those tile states with (A^2048)^(2^d), 256 tiles
+// of L samples is  A^L * (state before) + (state the run reaches from zero).  A lane owns 16 consecutive
+// samples, a workgroup a tile of 4096:
+//   1. iir_tile_state_kernel: every lane runs its 16 samples from zero state; a Kogge-Stone scan over the
+//      256 lanes with the constant matrices (A^16)^(2^d) gives the state the tile reaches from zero.
+//   2. iir_tile_scan_kernel: one workgroup per channel scans those tile states with (A^4096)^(2^d), 256 tiles
 //      per pass, and leaves in their place the state every tile starts from.
 //   3. iir_apply_kernel: as 1., with the tile's true starting state folded into lane 0; every lane then knows
-//      the state it starts from and runs its 8 samples again from it, which yields the outputs.
+//      the state it starts from and runs its 16 samples again from it, which yields the outputs.
 // HBM traffic: w is read twice and y written once (24 bytes per sample).
 //
 // Sequential path (iir_seq_kernel): one lane per channel, samples in order, staged through LDS in 64x64
@@ -25,8 +25,9 @@ namespace {
 
 constexpr int kBlock = 256;
 constexpr int kR = kIirTile / kBlock;  // samples per lane
-static_assert(kR == 8 && (1 << kIirLevels) == kBlock, "scan geometry");
-constexpr int kImg = kIirTile + 2 * (kIirTile / 8);  // tile image: sample q at q + 2*(q/8) (lane stride 80 bytes)
+static_assert(kR == 16 && (1 << kIirLevels) == kBlock, "scan geometry");
+constexpr int kLaneStride = kR + 2;                  // tile image: sample q at q + 2*(q/16); lanes 144 bytes apart,
+constexpr int kImg = kBlock * kLaneStride;           // which keeps 16-byte LDS reads aligned and conflict-free
 
 template <bool EXACT> __device__ __forceinline__ double tail_step(double a, double yp, double acc) {
     if constexpr (EXACT)
@@ -64,12 +65,6 @@ __device__ __forceinline__ dd dd_add(dd a, dd b) {
     s.lo += a.lo + b.lo;
     return quick_two_sum(s.hi, s.lo);
 }
-__device__ __forceinline__ dd dd_mul_d(dd a, double b) {
-    const double p = a.hi * b;
-    double e = __builtin_fma(a.hi, b, -p);
-    e = __builtin_fma(a.lo, b, e);
-    return quick_two_sum(p, e);
-}
 __device__ __forceinline__ dd dd_mul(dd a, dd b) {
     const double p = a.hi * b.hi;
     double e = __builtin_fma(a.hi, b.hi, -p);
@@ -78,15 +73,23 @@ __device__ __forceinline__ dd dd_mul(dd a, dd b) {
     return quick_two_sum(p, e);
 }
 
-// s <- s + M * p, accumulated in double-double, rounded to double once per component
+// s <- s + M * p as a compensated dot product (products and running sum split exactly into a leading part
+// and an error term; the error terms are added up apart), rounded to double once per component
 template <int P>
 __device__ __forceinline__ void add_matvec(double (&s)[P], const IirMatrix& M, const double (&p)[P]) {
 #pragma unroll
     for (int r = 0; r < P; ++r) {
-        dd acc{s[r], 0.0};
+        double lead = s[r], rest = 0.0;
 #pragma unroll
-        for (int c = 0; c < P; ++c) acc = dd_add(acc, dd_mul_d(dd{M.hi[r][c], M.lo[r][c]}, p[c]));
-        s[r] = acc.hi;
+        for (int c = 0; c < P; ++c) {
+            const double prod = M.hi[r][c] * p[c];
+            double e = __builtin_fma(M.hi[r][c], p[c], -prod);
+            e = __builtin_fma(M.lo[r][c], p[c], e);
+            const dd t = two_sum(lead, prod);
+            lead = t.hi;
+            rest += t.lo + e;
+        }
+        s[r] = lead + rest;
     }
 }
 
@@ -111,16 +114,24 @@ __device__ __forceinline__ void scan_states(double (&s)[P], const IirMatrix* M, 
     }
 }
 
-// Loads the tile into the LDS image (zeros past the end of the channel) and returns the lane's 8 samples.
-__device__ __forceinline__ void load_tile(const double* __restrict__ yt, long long left, double* img, int tid,
-                                          double (&w)[kR]) {
+// Loads the tile into the LDS image (zeros past the end of the channel) and returns the lane's 16 samples.
+__device__ __forceinline__ void load_tile(const double* __restrict__ yt, long long left, bool vec2, double* img,
+                                          int tid, double (&w)[kR]) {
+    if (vec2 && left >= kIirTile) {  // whole tile, 16-byte loads (uniform branch)
 #pragma unroll
-    for (int i = 0; i < kR; ++i) {
-        const int q = tid + i * kBlock;
-        img[q + 2 * (q >> 3)] = q < left ? yt[q] : 0.0;
+        for (int i = 0; i < kR / 2; ++i) {
+            const int q = 2 * (tid + i * kBlock);
+            *reinterpret_cast<double2*>(img + q + 2 * (q >> 4)) = reinterpret_cast<const double2*>(yt)[tid + i * kBlock];
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < kR; ++i) {
+            const int q = tid + i * kBlock;
+            img[q + 2 * (q >> 4)] = q < left ? yt[q] : 0.0;
+        }
     }
     __syncthreads();
-    const double2* mine = reinterpret_cast<const double2*>(img + 10 * tid);
+    const double2* mine = reinterpret_cast<const double2*>(img + kLaneStride * tid);
 #pragma unroll
     for (int i = 0; i < kR / 2; ++i) {
         const double2 v = mine[i];
@@ -133,7 +144,7 @@ __device__ __forceinline__ void locate(const IirShape& s, unsigned& chan, unsign
     tile = blockIdx.x - chan * s.tiles_per_chan;
 }
 
-// Computes (A^8)^(2^d) and (A^2048)^(2^d) by repeated squaring in double-double; one workgroup of 64
+// Computes (A^16)^(2^d) and (A^4096)^(2^d) by repeated squaring in double-double; one workgroup of 64
 // threads, thread = element.
 __global__ __launch_bounds__(64) void iir_tables_kernel(IirCoef coef, int order, IirTables* out) {
     __shared__ double mh[kIirMaxOrder][kIirMaxOrder], ml[kIirMaxOrder][kIirMaxOrder];
@@ -152,12 +163,12 @@ __global__ __launch_bounds__(64) void iir_tables_kernel(IirCoef coef, int order,
         return acc;
     };
     dd e{v, 0.0};
-    for (int i = 0; i < 3; ++i) e = square();  // A^8
+    for (int i = 0; i < 4; ++i) e = square();  // A^16
     for (int d = 0; d < kIirLevels; ++d) {
         out->lane[d].hi[r][c] = e.hi, out->lane[d].lo[r][c] = e.lo;
         e = square();
     }
-    // e = (A^8)^256 = A^2048
+    // e = (A^16)^256 = A^4096
     for (int d = 0; d < kIirLevels; ++d) {
         out->tile[d].hi[r][c] = e.hi, out->tile[d].lo[r][c] = e.lo;
         if (d + 1 < kIirLevels) e = square();
@@ -175,7 +186,7 @@ __global__ __launch_bounds__(kBlock) void iir_tile_state_kernel(IirCoef coef, co
     locate(s, chan, tile);
     const long long start = (long long)tile * kIirTile;
     double w[kR];
-    load_tile(y + (unsigned long long)chan * s.y_stride + start, s.n - start, img, tid, w);
+    load_tile(y + (unsigned long long)chan * s.y_stride + start, s.n - start, s.vec2 != 0, img, tid, w);
     double st[P];
 #pragma unroll
     for (int k = 0; k < P; ++k) st[k] = 0.0;
@@ -244,7 +255,7 @@ __global__ __launch_bounds__(kBlock) void iir_apply_kernel(IirCoef coef, double*
     const long long left = s.n - start;
     double* __restrict__ yt = y + (unsigned long long)chan * s.y_stride + start;
     double w[kR];
-    load_tile(yt, left, img, tid, w);
+    load_tile(yt, left, s.vec2 != 0, img, tid, w);
     double st[P], in[P];
 #pragma unroll
     for (int k = 0; k < P; ++k) st[k] = 0.0;
@@ -264,7 +275,7 @@ __global__ __launch_bounds__(kBlock) void iir_apply_kernel(IirCoef coef, double*
 #pragma unroll
         for (int k = 0; k < P; ++k) in[k] = buf[k * kBlock + tid - 1];
     }
-    double2* mine = reinterpret_cast<double2*>(img + 10 * tid);
+    double2* mine = reinterpret_cast<double2*>(img + kLaneStride * tid);
 #pragma unroll
     for (int i = 0; i < kR / 2; ++i) {
         const double a = advance<P>(in, coef, w[2 * i]);
@@ -272,10 +283,18 @@ __global__ __launch_bounds__(kBlock) void iir_apply_kernel(IirCoef coef, double*
         mine[i] = make_double2(a, b);
     }
     __syncthreads();
+    if (s.vec2 && left >= kIirTile) {
 #pragma unroll
-    for (int i = 0; i < kR; ++i) {
-        const int q = tid + i * kBlock;
-        if (q < left) yt[q] = img[q + 2 * (q >> 3)];
+        for (int i = 0; i < kR / 2; ++i) {
+            const int q = 2 * (tid + i * kBlock);
+            reinterpret_cast<double2*>(yt)[tid + i * kBlock] = *reinterpret_cast<const double2*>(img + q + 2 * (q >> 4));
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < kR; ++i) {
+            const int q = tid + i * kBlock;
+            if (q < left) yt[q] = img[q + 2 * (q >> 4)];
+        }
     }
 }
 
@@ -359,7 +378,7 @@ bool iir_tables_usable(const double* a, int order) {
     double m[kIirMaxOrder][kIirMaxOrder] = {}, t[kIirMaxOrder][kIirMaxOrder];
     for (int r = 0; r < order; ++r)
         for (int c = 0; c < order; ++c) m[r][c] = r == 0 ? -a[c] : (c == r - 1 ? 1.0 : 0.0);
-    for (int step = 0; step < 3 + 2 * kIirLevels - 1; ++step) {
+    for (int step = 0; step < 4 + 2 * kIirLevels - 1; ++step) {
         for (int r = 0; r < order; ++r)
             for (int c = 0; c < order; ++c) {
                 double acc = 0.0;

@@ -45,7 +45,7 @@ def designs():
     return out
 
 
-@pytest.mark.parametrize("n", [1, 2, 7, 8, 9, 255, 2047, 2048, 2049, 5000, 70001])
+@pytest.mark.parametrize("n", [1, 2, 7, 8, 9, 15, 16, 17, 255, 4095, 4096, 4097, 9000, 70001])
 def test_exact_mode_is_bit_identical(dsp, oracle, n):
     for b, a in designs():
         x = oracle.fill_splitmix(n, dsp.SEED, 11 * n)
@@ -54,7 +54,7 @@ def test_exact_mode_is_bit_identical(dsp, oracle, n):
         assert np.array_equal(bits(y), bits(ref)), (n, a.size)
 
 
-@pytest.mark.parametrize("n", [1, 5, 8, 9, 100, 2047, 2048, 2049, 4097, 70001, (1 << 20) + 3])
+@pytest.mark.parametrize("n", [1, 5, 8, 9, 16, 17, 100, 4095, 4096, 4097, 8193, 70001, (1 << 20) + 3])
 def test_block_parallel_tail_within_tolerance(dsp, oracle, n):
     for b, a in designs():
         x = oracle.fill_splitmix(n, dsp.SEED, 7 * n)
@@ -97,7 +97,7 @@ def test_batched_channels_are_independent(dsp, oracle):
     from scipy import signal
 
     b, a = signal.butter(4, 0.2)
-    for nchan, n in ((3, 1000), (70, 4099), (200, 333), (1, 3 * 2048)):
+    for nchan, n in ((3, 1000), (70, 4099), (200, 333), (1, 3 * 4096)):
         x = np.stack([oracle.fill_splitmix(n, dsp.SEED, c * n) for c in range(nchan)])
         ref = np.stack([oracle.lfilter(b, a, x[c]) for c in range(nchan)])
         assert np.array_equal(bits(dsp.lfilter_iir(b, a, x, exact=True)), bits(ref))
