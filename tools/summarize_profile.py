@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """Condenses a tools/profile.sh output directory into profiles/<tag>_kernel_stats.csv and
 profiles/<tag>_pmc_summary.json, and refreshes profiles/pmc_traffic.json for the workload.
-   python tools/summarize_profile.py gpurun_out/prof_r01c r01c batched255 <outputs_per_launch> <ntaps>"""
+   python tools/summarize_profile.py gpurun_out/prof_r01c r01c batched255 <units_per_launch> <ntaps> [bytes_per_unit flops_per_unit]
+(a unit is an output sample, 16 bytes and 2*ntaps flops, unless the two optional figures say otherwise:
+the wavelet bank counts input samples, 528 bytes and 2*34385 flops each; several kernels matching
+"fir_f64" in one step, as in the bank, are added up per step)"""
 import collections
 import csv
 import glob
@@ -12,6 +15,9 @@ import shutil
 import sys
 
 src, tag, workload, outputs, ntaps = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4]), int(sys.argv[5])
+bytes_per_unit = float(sys.argv[6]) if len(sys.argv) > 6 else 16.0
+flops_per_unit = float(sys.argv[7]) if len(sys.argv) > 7 else 2.0 * ntaps
+launches_per_step = int(sys.argv[8]) if len(sys.argv) > 8 else 1
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 prof = os.path.join(root, "profiles")
 os.makedirs(prof, exist_ok=True)
@@ -29,16 +35,16 @@ for name in ("sq1", "sq2", "fetch", "write", "grbm"):
             disp.add(r["Dispatch_Id"])
             spans[r["Dispatch_Id"]] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
     if name == "grbm":
-        out["grbm_pass_avg_launch_ns"] = sum(spans.values()) / len(spans)
+        out["grbm_pass_avg_launch_ns"] = sum(spans.values()) / len(spans) * launches_per_step
     for c, v in agg.items():
-        out["per_launch"][c] = v / len(disp)
+        out["per_launch"][c] = v / len(disp) * launches_per_step   # per step when a step is several launches
 pl = out["per_launch"]
 out["derived"] = {
     "hbm_read_bytes_per_launch": pl["FETCH_SIZE"] * 1024 * 2,
     "hbm_write_bytes_per_launch": pl["WRITE_SIZE"] * 1024,
     "note_fetch": "FETCH_SIZE is in KB and counts 64 B per 128-B request for 16-byte-per-lane streaming reads on gfx950: doubled",
-    "algorithmic_bytes_per_launch": 16 * outputs,
-    "algorithmic_flops_per_launch": 2 * ntaps * outputs,
+    "algorithmic_bytes_per_launch": bytes_per_unit * outputs,
+    "algorithmic_flops_per_launch": flops_per_unit * outputs,
     "lds_conflict_fraction": pl["SQ_LDS_BANK_CONFLICT"] / max(pl["SQ_LDS_IDX_ACTIVE"], 1),
     "clock_ghz_from_grbm": pl["GRBM_GUI_ACTIVE"] / 8 / out["grbm_pass_avg_launch_ns"],
     "note_clock": "GRBM_GUI_ACTIVE sums the 8 XCDs; divided by 8 and by the launch duration in the same pass",
