@@ -48,7 +48,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="batched255", choices=sorted(WORKLOADS) + ["cwt65"])
+    ap.add_argument("--workload", default="batched255", choices=sorted(WORKLOADS) + ["cwt65", "iir_biquad"])
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--exact", action="store_true", help="DSPX_FIR_EXACT arithmetic (separate mul/add)")
     ap.add_argument("--vector", action="store_true", help="force the vector-pipe kernel (DSPX_FIR_VECTOR)")
@@ -196,6 +196,96 @@ def run_cwt(args, rank, world, dev, dist, red_dev):
     print(json.dumps(res), flush=True)
 
 
+def butter2(wn: float):
+    """Second-order Butterworth low-pass (bilinear transform), cutoff wn with Nyquist = 1."""
+    k = np.tan(np.pi * wn / 2.0)
+    norm = 1.0 / (1.0 + np.sqrt(2.0) * k + k * k)
+    b0 = k * k * norm
+    return np.array([b0, 2.0 * b0, b0]), np.array([1.0, 2.0 * (k * k - 1.0) * norm, (1.0 - np.sqrt(2.0) * k + k * k) * norm])
+
+
+def run_iir(args, rank, world, dev, dist, red_dev):
+    """lfilter with a recursive part (reference dsp.hpp:366-368): 4096 channels x 2^20 samples through a biquad,
+    every rank its own batch (weak scaling)."""
+    import torch
+
+    import dsp_amd
+
+    nchan, n = 4096, 1 << 20
+    b, a = butter2(0.2)
+    bt = torch.from_numpy(b).to(dev)
+    x = torch.empty((nchan, n), dtype=torch.float64, device=dev)
+    y = torch.empty_like(x)
+    dsp_amd.fill_splitmix(x, dsp_amd.SEED, rank * nchan * n)
+
+    def step():
+        dsp_amd.lfilter_iir_device(bt, a, x, out=y, exact=args.exact)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    fence()
+    t0 = time.perf_counter()
+    ev[0].record()
+    for i in range(args.steps):
+        step()
+        ev[i + 1].record()
+    fence()
+    dt = time.perf_counter() - t0
+    kern_ms = float(np.mean([ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps)]))
+    t = torch.tensor([dt, kern_ms], dtype=torch.float64, device=red_dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if rank != 0:
+        return
+    dt_max, kern_ms = float(t[0]), float(t[1])
+    sec = kern_ms / 1e3
+    bytes_alg = 16.0 * nchan * n
+    res = {
+        "metric": "FP64 lfilter output GS/s (3-tap numerator, 2 poles)", "value": world * nchan * n * args.steps / dt_max / 1e9,
+        "unit": "GS/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt_max / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic (splitmix64 uniform [-1,1), generated on device, resident in HBM)",
+        "config": {"workload": "lfilter(b, a, x) with a recursive part: 4096 x 2^20 samples, Butterworth biquad (cutoff 0.2)",
+                   "nchan_per_gpu": nchan, "samples_per_channel": n, "nb": 3, "na": 3,
+                   "arithmetic": "exact (sequential, mul+sub)" if args.exact else "fma, block-parallel"},
+        "roofline": {"bound": "hbm", "achieved": bytes_alg / sec / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                     "frac": bytes_alg / sec / 1e9 / PEAK_HBM_GBS, "traffic": load_traffic("iir_biquad"),
+                     "kernel": "iir_tile_state_kernel + iir_tile_scan_kernel + iir_apply_kernel (FIR part fused)",
+                     "kernel_ms": kern_ms,
+                     "note": "algorithmic bytes = 16 per output (8 read + 8 written); the block-parallel evaluation "
+                             "reads the input twice, so it moves 24"},
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        from oracle.pyoracle import SEED, Oracle, Reference, reference_available
+
+        orc = Oracle()
+        cpu, kind, what = orc, "port", "oracle/fir_oracle.c gcc -O2 -ffp-contract=off (bit-identical to the reference loop)"
+        if reference_available():
+            try:
+                cpu, kind = Reference(), "reference"
+                what = "dsp::lfilter of the unmodified reference header (oracle/_ref, g++ -std=c++20 -O2 -ffp-contract=off)"
+            except OSError:
+                pass
+        m = 64                                   # bounded sample: the first 64 channels
+        xs = [orc.fill_splitmix(n, SEED, c * n) for c in range(m)]
+        t0 = time.perf_counter()
+        ref = [cpu.lfilter(b, a, xs[c]) for c in range(m)]
+        cdt = time.perf_counter() - t0
+        got = y[:m].cpu().numpy()
+        err = max(float(np.max(np.abs(got[c] - ref[c])) / np.max(np.abs(ref[c]))) for c in range(m))
+        res["cpu_baseline"] = {"value": m * n / cdt / 1e9, "unit": "GS/s", "cores": 1, "kind": kind,
+                               "sample": f"{m} channels x {n} samples of the same workload, {cdt:.1f} s, {what}",
+                               "gpu_vs_cpu_max_scaled_err": err}
+    print(json.dumps(res), flush=True)
+
+
 def load_traffic(workload: str):
     """HBM bytes per launch from the committed PMC summary, if one exists for this workload."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -237,8 +327,8 @@ def main() -> None:
         else:
             dist.init_process_group(backend=backend)
 
-    if args.workload == "cwt65":
-        run_cwt(args, rank, world, dev, dist, red_dev)
+    if args.workload in ("cwt65", "iir_biquad"):
+        (run_cwt if args.workload == "cwt65" else run_iir)(args, rank, world, dev, dist, red_dev)
         if world > 1:
             dist.barrier()
             dist.destroy_process_group()

@@ -114,8 +114,15 @@ size_t tail_workspace_bytes(const Tail& t, size_t nchan, size_t n) {
 
 // Applies the tail in place to d_y (which holds the FIR part).  d_state: per channel the `order` outputs
 // that precede y[0], oldest first (nullable).  d_work: tail_workspace_bytes() for the channels of one launch.
+// True when the numerator is short enough for the tail kernels to compute the FIR part themselves.
+bool tail_fuses_fir(const Tail& t, size_t nb, unsigned flags) {
+    return t.order && t.scan && nb >= 1 && nb <= (size_t)dspx::kIirMaxFusedTaps && !(flags & DSPX_FIR_MFMA);
+}
+
+// `front` (nullable): the FIR part is computed from x inside the tail kernels (tail_fuses_fir) instead of being
+// expected in d_y.
 int launch_tail(const Tail& t, double* d_y, size_t y_stride, const double* d_state, size_t state_stride, size_t nchan,
-                size_t n, void* d_work, hipStream_t stream) {
+                size_t n, void* d_work, hipStream_t stream, const dspx::IirFront* front = nullptr) {
     if (t.order == 0 || nchan == 0 || n == 0) return DSPX_OK;
     const size_t tiles = (n + dspx::kIirTile - 1) / dspx::kIirTile;
     if (tiles > kMaxGrid) return fail(DSPX_ERR_INVALID, "n too large for one launch: %zu", n);
@@ -129,12 +136,29 @@ int launch_tail(const Tail& t, double* d_y, size_t y_stride, const double* d_sta
         s.nchan = (unsigned)std::min(chans_per_launch, nchan - c0);
         s.vec2 = aligned16(d_y) && y_stride % 2 == 0;
         const double* st = d_state ? d_state + c0 * state_stride : nullptr;
-        if (t.scan)  // launches on one stream run in order, so the workspace is reused from launch to launch
-            DSPX_HIP(dspx::launch_iir_scan(t.coef, t.order, d_y + c0 * y_stride, st, s, d_work, stream));
+        if (t.scan) {  // launches on one stream run in order, so the workspace is reused from launch to launch
+            dspx::IirFront f{};
+            if (front) {
+                f = *front;
+                f.x += c0 * f.x_stride;
+                if (f.xhist) f.xhist += c0 * f.xhist_stride;
+            }
+            DSPX_HIP(dspx::launch_iir_scan(t.coef, t.order, d_y + c0 * y_stride, st, s, front ? &f : nullptr, d_work,
+                                           stream));
+        }
         else
             DSPX_HIP(dspx::launch_iir_sequential(t.coef, t.order, d_y + c0 * y_stride, st, s, t.exact, stream));
     }
     return DSPX_OK;
+}
+
+dspx::IirFront make_front(const double* d_b, size_t nb, const double* d_x, size_t x_stride, const double* d_xhist,
+                          size_t xhist_stride) {
+    dspx::IirFront f{};
+    f.x = d_x, f.xhist = d_xhist, f.x_stride = x_stride, f.xhist_stride = xhist_stride;
+    f.b = d_b, f.nb = (int)nb;
+    f.vec2 = aligned16(d_x) && x_stride % 2 == 0;
+    return f;
 }
 
 int check_common(const double* taps, size_t ntaps, const void* x, const void* y, size_t nchan, size_t n,
@@ -382,10 +406,12 @@ struct Pipeline {
         DSPX_HIP(hipMemcpyAsync(s.d_in, s.pin_in, (g.taps_pad + g.in_pitch * p.cnt) * sizeof(double),
                                 hipMemcpyHostToDevice, s.stream));
         const double* d_rows = s.d_in + g.taps_pad;
-        if (int lrc = launch_dev(s.d_in, ntaps, d_rows + g.hl_pad, g.in_pitch,
-                                 with_hist ? d_rows + (g.hl_pad - g.hl) : nullptr, g.in_pitch, s.d_out, g.out_pitch,
-                                 p.cnt, p.len, flags, s.stream))
-            return lrc;
+        const bool fused = tail_fuses_fir(*tail, ntaps, flags);
+        const double* d_xhist = with_hist ? d_rows + (g.hl_pad - g.hl) : nullptr;
+        if (!fused)
+            if (int lrc = launch_dev(s.d_in, ntaps, d_rows + g.hl_pad, g.in_pitch, d_xhist, g.in_pitch, s.d_out,
+                                     g.out_pitch, p.cnt, p.len, flags, s.stream))
+                return lrc;
         if (tail->order) {
             // a piece that continues a channel starts from the last outputs of the piece before it, which
             // runs on another stream: wait for it (pieces of a channel are issued in order by one thread)
@@ -394,8 +420,9 @@ struct Pipeline {
                 DSPX_HIP(hipStreamWaitEvent(s.stream, eng->slots[(i - 1) % kSlots].done, 0));
                 d_state = eng->d_tail_state;
             }
+            const dspx::IirFront front = make_front(s.d_in, ntaps, d_rows + g.hl_pad, g.in_pitch, d_xhist, g.in_pitch);
             if (int trc = launch_tail(*tail, s.d_out, g.out_pitch, d_state, (size_t)tail->order, p.cnt, p.len, s.d_work,
-                                      s.stream))
+                                      s.stream, fused ? &front : nullptr))
                 return trc;
             const bool continues = i + 1 < pieces->size() && (*pieces)[i + 1].s0 > 0;
             if (continues)  // cnt == 1 and len >= order here
@@ -639,8 +666,20 @@ int dspx_lfilter_f64_dev(const double* d_b, size_t nb, const double* a, size_t n
     Tail tail;
     if (int rc = dspx::check_flags(flags)) return rc;
     if (int rc = make_tail(a, na, flags, tail)) return rc;
-    if (int rc = dspx_fir_f64_dev(d_b, nb, d_x, x_stride, d_xhist, xhist_stride, d_y, y_stride, nchan, n, flags, stream))
+    const bool fused = tail_fuses_fir(tail, nb, flags);
+    if (fused) {  // the checks dspx_fir_f64_dev would make; the tail kernels read x themselves
+        if (int rc = check_common(d_b, nb, d_x, d_y, nchan, n, flags)) return rc;
+        if (nchan > 1 && (x_stride < n || y_stride < n))
+            return fail(DSPX_ERR_INVALID, "channel stride smaller than n (%zu): x %zu, y %zu", n, x_stride, y_stride);
+        if (d_xhist && nchan > 1 && nb > 1 && xhist_stride < nb - 1)
+            return fail(DSPX_ERR_INVALID, "hist_stride (%zu) < ntaps-1", xhist_stride);
+        if (nchan && n && ranges_overlap(d_x, ((nchan - 1) * x_stride + n) * sizeof(double), d_y,
+                                         ((nchan - 1) * y_stride + n) * sizeof(double)))
+            return fail(DSPX_ERR_INVALID, "d_x and d_y overlap");
+    } else if (int rc = dspx_fir_f64_dev(d_b, nb, d_x, x_stride, d_xhist, xhist_stride, d_y, y_stride, nchan, n, flags,
+                                         stream)) {
         return rc;
+    }
     if (tail.order == 0 || nchan == 0 || n == 0) return DSPX_OK;
     if (d_yhist && nchan > 1 && yhist_stride < (size_t)tail.order)
         return fail(DSPX_ERR_INVALID, "yhist_stride (%zu) < na-1", yhist_stride);
@@ -648,7 +687,9 @@ int dspx_lfilter_f64_dev(const double* d_b, size_t nb, const double* a, size_t n
     if (need && (!d_work || work_bytes < need))
         return fail(DSPX_ERR_INVALID, "workspace of %zu bytes needed (dspx_lfilter_workspace_bytes), got %zu", need,
                     d_work ? work_bytes : (size_t)0);
-    return launch_tail(tail, d_y, y_stride, d_yhist, yhist_stride, nchan, n, d_work, static_cast<hipStream_t>(stream));
+    const dspx::IirFront front = make_front(d_b, nb, d_x, x_stride, d_xhist, xhist_stride);
+    return launch_tail(tail, d_y, y_stride, d_yhist, yhist_stride, nchan, n, d_work, static_cast<hipStream_t>(stream),
+                       fused ? &front : nullptr);
 }
 
 long dspx_fir_plan(size_t nchan, size_t n, int ngpus, dspx_piece* out, size_t cap) {

@@ -31,6 +31,18 @@ struct IirTables {
     IirMatrix tile[kIirLevels];
 };
 
+// The FIR part, when the tail kernels compute it on the fly from x instead of reading it from y (short
+// numerators: x is then read twice and y written once, 24 bytes per sample instead of 40).  nb == 0: not fused.
+constexpr int kIirMaxFusedTaps = 16;
+struct IirFront {
+    const double* x;
+    const double* xhist;              // per channel the nb-1 samples before x[0], oldest first (nullable)
+    unsigned long long x_stride, xhist_stride;
+    const double* b;                  // nb taps in device memory
+    int nb;
+    int vec2;                         // x is 16-byte aligned and x_stride is even
+};
+
 struct IirShape {
     unsigned long long y_stride;      // elements between channels of y
     unsigned long long state_stride;  // elements between channels of the incoming state
@@ -50,8 +62,10 @@ bool iir_tables_usable(const double* a, int order);
 
 // Block-parallel path (fused multiply-adds; rounding differs from the sequential loop).  `work` holds
 // iir_workspace_bytes(); `state_in` (nullable) holds per channel the P outputs that precede y[0], oldest first.
+// `front` (nullable): compute the FIR part from x on the fly (one fused multiply-add per tap, taps ascending,
+// as the vector-pipe FIR kernel does) instead of expecting it in y.
 hipError_t launch_iir_scan(const IirCoef& coef, int order, double* y, const double* state_in, const IirShape& shape,
-                           void* work, hipStream_t stream);
+                           const IirFront* front, void* work, hipStream_t stream);
 
 // One lane per channel, samples in order.  exact: product and subtraction rounded separately, j ascending,
 // bit-identical to dsp.hpp:366-368; otherwise one fused multiply-add per coefficient.

@@ -10,7 +10,9 @@
 //      per pass, and leaves in their place the state every tile starts from.
 //   3. iir_apply_kernel: as 1., with the tile's true starting state folded into lane 0; every lane then knows
 //      the state it starts from and runs its 16 samples again from it, which yields the outputs.
-// HBM traffic: w is read twice and y written once (24 bytes per sample).
+// HBM traffic: w is read twice and y written once (24 bytes per sample, on top of the FIR pass's 16).  For a
+// numerator of at most 16 taps the kernels of 1. and 3. compute w from x on the fly instead (FUSED): x is read
+// twice, y written once, and no FIR pass runs.
 //
 // Sequential path (iir_seq_kernel): one lane per channel, samples in order, staged through LDS in 64x64
 // blocks so that global accesses stay coalesced; with EXACT it is bit-identical to the reference loop.
@@ -27,7 +29,8 @@ constexpr int kBlock = 256;
 constexpr int kR = kIirTile / kBlock;  // samples per lane
 static_assert(kR == 16 && (1 << kIirLevels) == kBlock, "scan geometry");
 constexpr int kLaneStride = kR + 2;                  // tile image: sample q at q + 2*(q/16); lanes 144 bytes apart,
-constexpr int kImg = kBlock * kLaneStride;           // which keeps 16-byte LDS reads aligned and conflict-free
+constexpr int kImg = (kBlock + 1) * kLaneStride;     // which keeps 16-byte LDS reads aligned and conflict-free;
+                                                     // one more slot in front holds the 16 samples before the tile
 
 template <bool EXACT> __device__ __forceinline__ double tail_step(double a, double yp, double acc) {
     if constexpr (EXACT)
@@ -114,29 +117,82 @@ __device__ __forceinline__ void scan_states(double (&s)[P], const IirMatrix* M, 
     }
 }
 
-// Loads the tile into the LDS image (zeros past the end of the channel) and returns the lane's 16 samples.
-__device__ __forceinline__ void load_tile(const double* __restrict__ yt, long long left, bool vec2, double* img,
-                                          int tid, double (&w)[kR]) {
+// Loads the tile into the LDS image (zeros past the end of the channel): sample q of the tile at
+// kLaneStride + q + 2*(q/16), i.e. lane t's samples in slot t + 1.
+__device__ __forceinline__ void stage_tile(const double* __restrict__ src, long long left, bool vec2, double* img,
+                                           int tid) {
+    double* body = img + kLaneStride;
     if (vec2 && left >= kIirTile) {  // whole tile, 16-byte loads (uniform branch)
 #pragma unroll
         for (int i = 0; i < kR / 2; ++i) {
             const int q = 2 * (tid + i * kBlock);
-            *reinterpret_cast<double2*>(img + q + 2 * (q >> 4)) = reinterpret_cast<const double2*>(yt)[tid + i * kBlock];
+            *reinterpret_cast<double2*>(body + q + 2 * (q >> 4)) = reinterpret_cast<const double2*>(src)[tid + i * kBlock];
         }
     } else {
 #pragma unroll
         for (int i = 0; i < kR; ++i) {
             const int q = tid + i * kBlock;
-            img[q + 2 * (q >> 4)] = q < left ? yt[q] : 0.0;
+            body[q + 2 * (q >> 4)] = q < left ? src[q] : 0.0;
         }
     }
-    __syncthreads();
-    const double2* mine = reinterpret_cast<const double2*>(img + kLaneStride * tid);
+}
+
+// The lane's 16 values of the FIR part: read from the staged tile, or (FUSED) computed from the staged input
+// and the 16 samples before the lane's own, taps ascending, one fused multiply-add per tap.
+template <bool FUSED>
+__device__ __forceinline__ void lane_fir_part(const double* img, int tid, const IirFront& f, double (&w)[kR]) {
+    const double2* mine = reinterpret_cast<const double2*>(img + kLaneStride * (tid + 1));
+    if constexpr (!FUSED) {
 #pragma unroll
-    for (int i = 0; i < kR / 2; ++i) {
-        const double2 v = mine[i];
-        w[2 * i] = v.x, w[2 * i + 1] = v.y;
+        for (int i = 0; i < kR / 2; ++i) {
+            const double2 v = mine[i];
+            w[2 * i] = v.x, w[2 * i + 1] = v.y;
+        }
+    } else {
+        double X[2 * kR];
+        const double2* prev = reinterpret_cast<const double2*>(img + kLaneStride * tid);
+#pragma unroll
+        for (int i = 0; i < kR / 2; ++i) {
+            const double2 p = prev[i], v = mine[i];
+            X[2 * i] = p.x, X[2 * i + 1] = p.y;
+            X[kR + 2 * i] = v.x, X[kR + 2 * i + 1] = v.y;
+        }
+#pragma unroll
+        for (int t = 0; t < kR; ++t) w[t] = 0.0;
+#pragma unroll
+        for (int j = 0; j < kIirMaxFusedTaps; ++j) {
+            if (j < f.nb) {  // uniform
+                const double bj = f.b[j];
+#pragma unroll
+                for (int t = 0; t < kR; ++t) w[t] = __builtin_fma(bj, X[kR + t - j], w[t]);
+            }
+        }
     }
+}
+
+// Stages what a tile needs and returns the lane's FIR part.  FUSED: the input tile and the 16 samples before
+// it (from x, from the history in front of x, or zeros).
+template <bool FUSED>
+__device__ __forceinline__ void load_fir_part(const double* __restrict__ y, const IirFront& f, const IirShape& s,
+                                              unsigned chan, long long start, double* img, int tid, double (&w)[kR]) {
+    static_assert(kIirMaxFusedTaps - 1 <= kR, "the slot in front of the tile holds the samples the taps reach");
+    if constexpr (FUSED) {
+        const double* __restrict__ xc = f.x + (unsigned long long)chan * f.x_stride;
+        stage_tile(xc + start, s.n - start, f.vec2 != 0, img, tid);
+        if (tid < kR) {
+            const long long g = start - kR + tid;
+            double v = 0.0;
+            if (g >= 0)
+                v = xc[g];
+            else if (f.xhist != nullptr && g >= -(long long)(f.nb - 1))
+                v = f.xhist[(unsigned long long)chan * f.xhist_stride + (f.nb - 1) + g];
+            img[tid] = v;
+        }
+    } else {
+        stage_tile(y + (unsigned long long)chan * s.y_stride + start, s.n - start, s.vec2 != 0, img, tid);
+    }
+    __syncthreads();
+    lane_fir_part<FUSED>(img, tid, f, w);
 }
 
 __device__ __forceinline__ void locate(const IirShape& s, unsigned& chan, unsigned& tile) {
@@ -175,8 +231,9 @@ __global__ __launch_bounds__(64) void iir_tables_kernel(IirCoef coef, int order,
     }
 }
 
-template <int P>
-__global__ __launch_bounds__(kBlock) void iir_tile_state_kernel(IirCoef coef, const double* __restrict__ y,
+template <int P, bool FUSED>
+__global__ __launch_bounds__(kBlock) void iir_tile_state_kernel(IirCoef coef, IirFront front,
+                                                                const double* __restrict__ y,
                                                                 const IirTables* __restrict__ tables,
                                                                 double* __restrict__ states, IirShape s) {
     __shared__ __align__(16) double img[kImg];
@@ -186,7 +243,7 @@ __global__ __launch_bounds__(kBlock) void iir_tile_state_kernel(IirCoef coef, co
     locate(s, chan, tile);
     const long long start = (long long)tile * kIirTile;
     double w[kR];
-    load_tile(y + (unsigned long long)chan * s.y_stride + start, s.n - start, s.vec2 != 0, img, tid, w);
+    load_fir_part<FUSED>(y, front, s, chan, start, img, tid, w);
     double st[P];
 #pragma unroll
     for (int k = 0; k < P; ++k) st[k] = 0.0;
@@ -242,8 +299,8 @@ __global__ __launch_bounds__(kBlock) void iir_tile_scan_kernel(const IirTables* 
     }
 }
 
-template <int P>
-__global__ __launch_bounds__(kBlock) void iir_apply_kernel(IirCoef coef, double* __restrict__ y,
+template <int P, bool FUSED>
+__global__ __launch_bounds__(kBlock) void iir_apply_kernel(IirCoef coef, IirFront front, double* __restrict__ y,
                                                            const IirTables* __restrict__ tables,
                                                            const double* __restrict__ states, IirShape s) {
     __shared__ __align__(16) double img[kImg];
@@ -255,7 +312,7 @@ __global__ __launch_bounds__(kBlock) void iir_apply_kernel(IirCoef coef, double*
     const long long left = s.n - start;
     double* __restrict__ yt = y + (unsigned long long)chan * s.y_stride + start;
     double w[kR];
-    load_tile(yt, left, s.vec2 != 0, img, tid, w);
+    load_fir_part<FUSED>(y, front, s, chan, start, img, tid, w);
     double st[P], in[P];
 #pragma unroll
     for (int k = 0; k < P; ++k) st[k] = 0.0;
@@ -275,7 +332,8 @@ __global__ __launch_bounds__(kBlock) void iir_apply_kernel(IirCoef coef, double*
 #pragma unroll
         for (int k = 0; k < P; ++k) in[k] = buf[k * kBlock + tid - 1];
     }
-    double2* mine = reinterpret_cast<double2*>(img + kLaneStride * tid);
+    if constexpr (FUSED) __syncthreads();  // every lane has read its neighbour's input before outputs replace it
+    double2* mine = reinterpret_cast<double2*>(img + kLaneStride * (tid + 1));
 #pragma unroll
     for (int i = 0; i < kR / 2; ++i) {
         const double a = advance<P>(in, coef, w[2 * i]);
@@ -287,13 +345,14 @@ __global__ __launch_bounds__(kBlock) void iir_apply_kernel(IirCoef coef, double*
 #pragma unroll
         for (int i = 0; i < kR / 2; ++i) {
             const int q = 2 * (tid + i * kBlock);
-            reinterpret_cast<double2*>(yt)[tid + i * kBlock] = *reinterpret_cast<const double2*>(img + q + 2 * (q >> 4));
+            reinterpret_cast<double2*>(yt)[tid + i * kBlock] =
+                *reinterpret_cast<const double2*>(img + kLaneStride + q + 2 * (q >> 4));
         }
     } else {
 #pragma unroll
         for (int i = 0; i < kR; ++i) {
             const int q = tid + i * kBlock;
-            if (q < left) yt[q] = img[q + 2 * (q >> 4)];
+            if (q < left) yt[q] = img[kLaneStride + q + 2 * (q >> 4)];
         }
     }
 }
@@ -343,13 +402,20 @@ __global__ __launch_bounds__(kSeqChans) void iir_seq_kernel(IirCoef coef, double
 }
 
 template <int P>
-hipError_t scan_path(const IirCoef& coef, double* y, const double* state_in, const IirShape& s, IirTables* tables,
-                     double* states, hipStream_t stream) {
-    const unsigned total = s.nchan * s.tiles_per_chan;
+hipError_t scan_path(const IirCoef& coef, double* y, const double* state_in, const IirShape& s, const IirFront* front,
+                     IirTables* tables, double* states, hipStream_t stream) {
+    const dim3 tiles(s.nchan * s.tiles_per_chan), block(kBlock);
     hipLaunchKernelGGL(iir_tables_kernel, dim3(1), dim3(64), 0, stream, coef, P, tables);
-    hipLaunchKernelGGL(iir_tile_state_kernel<P>, dim3(total), dim3(kBlock), 0, stream, coef, y, tables, states, s);
-    hipLaunchKernelGGL(iir_tile_scan_kernel<P>, dim3(s.nchan), dim3(kBlock), 0, stream, tables, states, state_in, s);
-    hipLaunchKernelGGL(iir_apply_kernel<P>, dim3(total), dim3(kBlock), 0, stream, coef, y, tables, states, s);
+    if (front) {
+        hipLaunchKernelGGL((iir_tile_state_kernel<P, true>), tiles, block, 0, stream, coef, *front, y, tables, states, s);
+        hipLaunchKernelGGL(iir_tile_scan_kernel<P>, dim3(s.nchan), block, 0, stream, tables, states, state_in, s);
+        hipLaunchKernelGGL((iir_apply_kernel<P, true>), tiles, block, 0, stream, coef, *front, y, tables, states, s);
+    } else {
+        const IirFront none{};
+        hipLaunchKernelGGL((iir_tile_state_kernel<P, false>), tiles, block, 0, stream, coef, none, y, tables, states, s);
+        hipLaunchKernelGGL(iir_tile_scan_kernel<P>, dim3(s.nchan), block, 0, stream, tables, states, state_in, s);
+        hipLaunchKernelGGL((iir_apply_kernel<P, false>), tiles, block, 0, stream, coef, none, y, tables, states, s);
+    }
     return hipGetLastError();
 }
 
@@ -408,11 +474,11 @@ bool iir_tables_usable(const double* a, int order) {
     }
 
 hipError_t launch_iir_scan(const IirCoef& coef, int order, double* y, const double* state_in, const IirShape& shape,
-                           void* work, hipStream_t stream) {
+                           const IirFront* front, void* work, hipStream_t stream) {
     if (shape.nchan == 0 || shape.n == 0) return hipSuccess;
     IirTables* tables = static_cast<IirTables*>(work);
     double* states = reinterpret_cast<double*>(static_cast<char*>(work) + kTablesBytes);
-#define DSPX_IIR_SCAN(P) scan_path<P>(coef, y, state_in, shape, tables, states, stream)
+#define DSPX_IIR_SCAN(P) scan_path<P>(coef, y, state_in, shape, front, tables, states, stream)
     DSPX_IIR_DISPATCH(DSPX_IIR_SCAN)
 #undef DSPX_IIR_SCAN
 }

@@ -42,6 +42,10 @@ def designs():
     a[0] = 123.0                                                           # ignored by the reference
     out.append((b, a))
     out.append((np.array([1.0, 0.5, 0.25]), np.array([1.0, 0.0, 0.81])))   # resonator, poles at +-0.9j
+    # numerators of 16 taps (the longest the tail kernels compute themselves), 17 and 200 taps (separate FIR pass,
+    # vector and matrix pipe)
+    for nb in (16, 17, 200):
+        out.append((signal.firwin(nb, 0.3), np.array([1.0, -0.6, 0.2])))
     return out
 
 

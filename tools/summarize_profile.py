@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Condenses a tools/profile.sh output directory into profiles/<tag>_kernel_stats.csv and
 profiles/<tag>_pmc_summary.json, and refreshes profiles/pmc_traffic.json for the workload.
-   python tools/summarize_profile.py gpurun_out/prof_r01c r01c batched255 <units_per_launch> <ntaps> [bytes_per_unit flops_per_unit]
+   python tools/summarize_profile.py gpurun_out/prof_r01c r01c batched255 <units_per_launch> <ntaps> [bytes_per_unit flops_per_unit launches_per_step kernel_name_part]
 (a unit is an output sample, 16 bytes and 2*ntaps flops, unless the two optional figures say otherwise:
 the wavelet bank counts input samples, 528 bytes and 2*34385 flops each; several kernels matching
 "fir_f64" in one step, as in the bank, are added up per step)"""
@@ -18,6 +18,7 @@ src, tag, workload, outputs, ntaps = sys.argv[1], sys.argv[2], sys.argv[3], int(
 bytes_per_unit = float(sys.argv[6]) if len(sys.argv) > 6 else 16.0
 flops_per_unit = float(sys.argv[7]) if len(sys.argv) > 7 else 2.0 * ntaps
 launches_per_step = int(sys.argv[8]) if len(sys.argv) > 8 else 1
+pattern = sys.argv[9] if len(sys.argv) > 9 else "fir_f64"   # kernels of the step
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 prof = os.path.join(root, "profiles")
 os.makedirs(prof, exist_ok=True)
@@ -29,8 +30,8 @@ for name in ("sq1", "sq2", "fetch", "write", "grbm"):
     f = glob.glob(os.path.join(src, name, "*", "*_counter_collection.csv"))[0]
     agg, disp, spans = collections.defaultdict(float), set(), {}
     for r in csv.DictReader(open(f)):
-        if "fir_f64" in r["Kernel_Name"]:
-            out["kernel"] = re.search(r"fir_f64\w*(<[^>]*>)?", r["Kernel_Name"]).group(0)
+        if pattern in r["Kernel_Name"]:
+            out["kernel"] = re.search(pattern + r"\w*(<[^>]*>)?", r["Kernel_Name"]).group(0)
             agg[r["Counter_Name"]] += float(r["Counter_Value"])
             disp.add(r["Dispatch_Id"])
             spans[r["Dispatch_Id"]] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
