@@ -68,6 +68,15 @@ def shard(workload: str, rank: int, world: int, scaling: str):
     return nchan_total, rank * nchan_total, nchan_total * world * n
 
 
+def segment(n: int, rank: int, world: int):
+    """Samples [lo, hi) of a single stream that `rank` filters when the stream is sharded over `world` GPUs:
+    cuts on multiples of 4, so that every output's arithmetic is what one launch would do (the matrix pipe
+    groups taps in fours by an output's distance from the start of its call)."""
+    def cut(g):
+        return n if g == world else (n * g // world) & ~3
+    return cut(rank), cut(rank + 1)
+
+
 def cpu_baseline(taps: np.ndarray, n: int, nsamples: int, y_gpu) -> dict:
     """Times the CPU loop (single thread) on whole channels of the workload, and, since the CPU result
     is at hand, checks the GPU output of the same channels against it.  The loop is the reference's own
@@ -335,19 +344,37 @@ def main() -> None:
         return
 
     _, n, numtaps, cutoff, desc = WORKLOADS[args.workload]
-    nchan, chan0, units_per_step_all = shard(args.workload, rank, world, args.scaling)
-    if nchan == 0:
-        raise SystemExit(f"rank {rank}: no channels to filter (more ranks than channels)")
-
     taps_h = dsp_amd.firwin(numtaps, cutoff)
     taps = torch.from_numpy(taps_h).to(dev)
-    x = torch.empty((nchan, n), dtype=torch.float64, device=dev)
-    y = torch.empty((nchan, n), dtype=torch.float64, device=dev)
-    dsp_amd.fill_splitmix(x, dsp_amd.SEED, chan0 * n)
+    hist = None
+    segments = args.scaling == "strong" and world > 1 and WORKLOADS[args.workload][0] < world
+    if segments:
+        # fewer streams than GPUs: every rank filters a contiguous segment of every stream, with the
+        # ntaps-1 samples before it as history (generated locally, as a host sharder would slice them)
+        nchan, chan0 = WORKLOADS[args.workload][0], 0
+        units_per_step_all = nchan * n
+        lo, hi = segment(n, rank, world)
+        lead = min(lo, numtaps - 1)
+        buf = torch.empty((nchan, lead + hi - lo), dtype=torch.float64, device=dev)
+        for c in range(nchan):
+            dsp_amd.fill_splitmix(buf[c], dsp_amd.SEED, c * n + lo - lead)
+        x = buf[:, lead:]
+        if lo > 0:
+            hist = torch.zeros((nchan, numtaps - 1), dtype=torch.float64, device=dev)
+            hist[:, numtaps - 1 - lead:] = buf[:, :lead]
+        n_local = hi - lo
+    else:
+        nchan, chan0, units_per_step_all = shard(args.workload, rank, world, args.scaling)
+        if nchan == 0:
+            raise SystemExit(f"rank {rank}: no channels to filter")
+        x = torch.empty((nchan, n), dtype=torch.float64, device=dev)
+        dsp_amd.fill_splitmix(x, dsp_amd.SEED, chan0 * n)
+        n_local = n
+    y = torch.empty((nchan, n_local), dtype=torch.float64, device=dev)
     torch.cuda.synchronize()
 
     def step():
-        dsp_amd.fir_device(taps, x, out=y, exact=args.exact, mfma=False if args.vector else None)
+        dsp_amd.fir_device(taps, x, out=y, hist=hist, exact=args.exact, mfma=False if args.vector else None)
 
     def fence():
         torch.cuda.synchronize()
@@ -389,18 +416,19 @@ def main() -> None:
     if rank == 0:
         matrix = not args.exact and not args.vector and numtaps >= dsp_amd.MATRIX_PIPE_MIN_TAPS
         kernel_name = "fir_f64_mfma_kernel (v_mfma_f64_16x16x4_f64)" if matrix else "fir_f64_kernel (v_fma_f64)"
-        outputs_per_launch = nchan * n
+        outputs_per_launch = nchan * n_local
+        traffic = load_traffic(args.workload) if (n_local == n and nchan == WORKLOADS[args.workload][0]) else None
         flops = 2.0 * numtaps * outputs_per_launch
         bytes_alg = 16.0 * outputs_per_launch
         sec = kern_ms_max / 1e3
         fp64 = {"bound": "mfma", "achieved": flops / sec / 1e12, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
-                "frac": flops / sec / 1e12 / PEAK_FP64_TFLOPS, "traffic": load_traffic(args.workload),
+                "frac": flops / sec / 1e12 / PEAK_FP64_TFLOPS, "traffic": traffic,
                 "kernel": kernel_name, "kernel_ms": kern_ms_max,
                 "note": "MI355X FP64 peak: matrix pipe = vector pipe = 78.6 TFLOP/s, so one number bounds both kernels. "
                         "algorithmic flops = 2*ntaps per output (the Toeplitz-block kernel's multiplies by zero taps "
                         "are not counted)"}
         hbm = {"bound": "hbm", "achieved": bytes_alg / sec / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-               "frac": bytes_alg / sec / 1e9 / PEAK_HBM_GBS, "traffic": load_traffic(args.workload),
+               "frac": bytes_alg / sec / 1e9 / PEAK_HBM_GBS, "traffic": traffic,
                "kernel": kernel_name, "kernel_ms": kern_ms_max,
                "note": "algorithmic bytes = 16 per output (8 read + 8 written)"}
         # the binding roof is the one that allows fewer samples per second
@@ -422,7 +450,8 @@ def main() -> None:
             "data": "synthetic (splitmix64 uniform [-1,1), generated on device, resident in HBM)",
             "config": {"workload": desc, "nchan_per_gpu": nchan, "samples_per_channel": n, "ntaps": numtaps,
                        "arithmetic": "exact (mul+add)" if args.exact else ("fma, matrix pipe" if matrix else "fma, vector pipe"),
-                       "sharding": "none" if world == 1 else ("channels" if args.scaling == "strong" else "independent batch per GPU")},
+                       "sharding": "none" if world == 1 else ("segments with history" if segments else "channels" if args.scaling == "strong"
+                                                             else "independent batch per GPU")},
             "roofline": primary,
             "roofline_other": secondary,
         }

@@ -68,6 +68,12 @@ def test_bench_shard_arithmetic():
     assert total == 4096
     assert bench.shard("batched255", 3, 4, "weak") == (4096, 3 * 4096, 4 * (4096 << 20))
     assert bench.shard("batched255", 0, 1, "weak") == bench.shard("batched255", 0, 1, "strong")
+    # a single stream over several GPUs: contiguous segments, cuts on multiples of 4
+    for n, world in ((1 << 28, 8), (1 << 26, 3), (1001, 4)):
+        spans = [bench.segment(n, r, world) for r in range(world)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(a[1] == b[0] and a[1] % 4 == 0 for a, b in zip(spans, spans[1:]))
+        assert max(hi - lo for lo, hi in spans) - min(hi - lo for lo, hi in spans) <= 8
 
 
 def test_world_size_2_gloo(dsp):
