@@ -266,10 +266,10 @@ def run_iir(args, rank, world, dev, dist, red_dev):
                    "arithmetic": "exact (sequential, mul+sub)" if args.exact else "fma, block-parallel"},
         "roofline": {"bound": "hbm", "achieved": bytes_alg / sec / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                      "frac": bytes_alg / sec / 1e9 / PEAK_HBM_GBS, "traffic": load_traffic("iir_biquad"),
-                     "kernel": "iir_tile_state_kernel + iir_tile_scan_kernel + iir_apply_kernel (FIR part fused)",
+                     "kernel": "iir_seq_kernel after fir_f64_kernel" if args.exact else
+                               "iir_walk_kernel (one workgroup per channel, FIR part computed in the same pass)",
                      "kernel_ms": kern_ms,
-                     "note": "algorithmic bytes = 16 per output (8 read + 8 written); the block-parallel evaluation "
-                             "reads the input twice, so it moves 24"},
+                     "note": "algorithmic bytes = 16 per output (8 read + 8 written)"},
     }
     if world == 1 and not args.no_cpu_baseline:
         from oracle.pyoracle import SEED, Oracle, Reference, reference_available

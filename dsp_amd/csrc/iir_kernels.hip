@@ -12,7 +12,8 @@
 //      the state it starts from and runs its 16 samples again from it, which yields the outputs.
 // HBM traffic: w is read twice and y written once (24 bytes per sample, on top of the FIR pass's 16).  For a
 // numerator of at most 16 taps the kernels of 1. and 3. compute w from x on the fly instead (FUSED): x is read
-// twice, y written once, and no FIR pass runs.
+// twice, y written once, and no FIR pass runs.  With many channels (iir_walk_kernel) a workgroup walks a whole
+// channel and carries the state from tile to tile itself: one read and one write per sample.
 //
 // Sequential path (iir_seq_kernel): one lane per channel, samples in order, staged through LDS in 64x64
 // blocks so that global accesses stay coalesced; with EXACT it is bit-identical to the reference loop.
@@ -299,40 +300,39 @@ __global__ __launch_bounds__(kBlock) void iir_tile_scan_kernel(const IirTables* 
     }
 }
 
+// One tile, start to finish: stage, run every lane from zero, join the lane states with the tile's starting
+// state `in` folded into lane 0, run every lane again from the state it really starts from, store.  On return
+// `in` holds the state the tile ends in (every thread has it).
 template <int P, bool FUSED>
-__global__ __launch_bounds__(kBlock) void iir_apply_kernel(IirCoef coef, IirFront front, double* __restrict__ y,
-                                                           const IirTables* __restrict__ tables,
-                                                           const double* __restrict__ states, IirShape s) {
-    __shared__ __align__(16) double img[kImg];
-    __shared__ double buf[2 * P * kBlock];
-    const int tid = threadIdx.x;
-    unsigned chan, tile;
-    locate(s, chan, tile);
+__device__ __forceinline__ void apply_tile(const IirCoef& coef, const IirFront& front, double* __restrict__ y,
+                                           const IirTables* __restrict__ tables, const IirShape& s, unsigned chan,
+                                           unsigned tile, double (&in)[P], double* img, double* buf, double* last,
+                                           int tid) {
     const long long start = (long long)tile * kIirTile;
     const long long left = s.n - start;
     double* __restrict__ yt = y + (unsigned long long)chan * s.y_stride + start;
     double w[kR];
     load_fir_part<FUSED>(y, front, s, chan, start, img, tid, w);
-    double st[P], in[P];
+    double st[P];
 #pragma unroll
     for (int k = 0; k < P; ++k) st[k] = 0.0;
 #pragma unroll
     for (int t = 0; t < kR; ++t) advance<P>(st, coef, w[t]);
-    const double* src = states + ((unsigned long long)chan * s.tiles_per_chan + tile) * P;
-#pragma unroll
-    for (int k = 0; k < P; ++k) in[k] = src[k];  // the state the tile starts from
     if (tid == 0) add_matvec<P>(st, tables->lane[0], in);
     scan_states<P>(st, tables->lane, buf, tid);
-    // a lane starts from what the lane before it ends in
+    // a lane starts from what the lane before it ends in; the last lane ends in the tile's final state
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < P; ++k) buf[k * kBlock + tid] = st[k];
+    if (tid == kBlock - 1) {
+#pragma unroll
+        for (int k = 0; k < P; ++k) last[k] = st[k];
+    }
     __syncthreads();
     if (tid > 0) {
 #pragma unroll
         for (int k = 0; k < P; ++k) in[k] = buf[k * kBlock + tid - 1];
     }
-    if constexpr (FUSED) __syncthreads();  // every lane has read its neighbour's input before outputs replace it
     double2* mine = reinterpret_cast<double2*>(img + kLaneStride * (tid + 1));
 #pragma unroll
     for (int i = 0; i < kR / 2; ++i) {
@@ -354,6 +354,46 @@ __global__ __launch_bounds__(kBlock) void iir_apply_kernel(IirCoef coef, IirFron
             const int q = tid + i * kBlock;
             if (q < left) yt[q] = img[kLaneStride + q + 2 * (q >> 4)];
         }
+    }
+#pragma unroll
+    for (int k = 0; k < P; ++k) in[k] = last[k];
+}
+
+template <int P, bool FUSED>
+__global__ __launch_bounds__(kBlock) void iir_apply_kernel(IirCoef coef, IirFront front, double* __restrict__ y,
+                                                           const IirTables* __restrict__ tables,
+                                                           const double* __restrict__ states, IirShape s) {
+    __shared__ __align__(16) double img[kImg];
+    __shared__ double buf[2 * P * kBlock];
+    __shared__ double last[P];
+    const int tid = threadIdx.x;
+    unsigned chan, tile;
+    locate(s, chan, tile);
+    const double* src = states + ((unsigned long long)chan * s.tiles_per_chan + tile) * P;
+    double in[P];
+#pragma unroll
+    for (int k = 0; k < P; ++k) in[k] = src[k];  // the state the tile starts from
+    apply_tile<P, FUSED>(coef, front, y, tables, s, chan, tile, in, img, buf, last, tid);
+}
+
+// Many channels: one workgroup walks a whole channel tile by tile and carries the state itself, so every
+// sample is read once and written once and one scan per tile suffices (no tile states, no second pass).
+template <int P, bool FUSED>
+__global__ __launch_bounds__(kBlock) void iir_walk_kernel(IirCoef coef, IirFront front, double* __restrict__ y,
+                                                          const IirTables* __restrict__ tables,
+                                                          const double* __restrict__ state_in, IirShape s) {
+    __shared__ __align__(16) double img[kImg];
+    __shared__ double buf[2 * P * kBlock];
+    __shared__ double last[P];
+    const int tid = threadIdx.x;
+    const unsigned chan = blockIdx.x;
+    double in[P];
+#pragma unroll
+    for (int k = 0; k < P; ++k)  // state_in is oldest first
+        in[k] = state_in ? state_in[(unsigned long long)chan * s.state_stride + (P - 1 - k)] : 0.0;
+    for (unsigned tile = 0; tile < s.tiles_per_chan; ++tile) {
+        apply_tile<P, FUSED>(coef, front, y, tables, s, chan, tile, in, img, buf, last, tid);
+        __syncthreads();  // the image and `last` are free for the next tile
     }
 }
 
@@ -401,21 +441,31 @@ __global__ __launch_bounds__(kSeqChans) void iir_seq_kernel(IirCoef coef, double
     }
 }
 
+// From this many channels on a launch has enough workgroups when each walks one channel.
+constexpr unsigned kWalkMinChans = 1024;
+
 template <int P>
 hipError_t scan_path(const IirCoef& coef, double* y, const double* state_in, const IirShape& s, const IirFront* front,
                      IirTables* tables, double* states, hipStream_t stream) {
     const dim3 tiles(s.nchan * s.tiles_per_chan), block(kBlock);
+    const IirFront f = front ? *front : IirFront{};
     hipLaunchKernelGGL(iir_tables_kernel, dim3(1), dim3(64), 0, stream, coef, P, tables);
-    if (front) {
-        hipLaunchKernelGGL((iir_tile_state_kernel<P, true>), tiles, block, 0, stream, coef, *front, y, tables, states, s);
-        hipLaunchKernelGGL(iir_tile_scan_kernel<P>, dim3(s.nchan), block, 0, stream, tables, states, state_in, s);
-        hipLaunchKernelGGL((iir_apply_kernel<P, true>), tiles, block, 0, stream, coef, *front, y, tables, states, s);
-    } else {
-        const IirFront none{};
-        hipLaunchKernelGGL((iir_tile_state_kernel<P, false>), tiles, block, 0, stream, coef, none, y, tables, states, s);
-        hipLaunchKernelGGL(iir_tile_scan_kernel<P>, dim3(s.nchan), block, 0, stream, tables, states, state_in, s);
-        hipLaunchKernelGGL((iir_apply_kernel<P, false>), tiles, block, 0, stream, coef, none, y, tables, states, s);
+    if (s.nchan >= kWalkMinChans) {
+        if (front)
+            hipLaunchKernelGGL((iir_walk_kernel<P, true>), dim3(s.nchan), block, 0, stream, coef, f, y, tables, state_in, s);
+        else
+            hipLaunchKernelGGL((iir_walk_kernel<P, false>), dim3(s.nchan), block, 0, stream, coef, f, y, tables, state_in, s);
+        return hipGetLastError();
     }
+    if (front)
+        hipLaunchKernelGGL((iir_tile_state_kernel<P, true>), tiles, block, 0, stream, coef, f, y, tables, states, s);
+    else
+        hipLaunchKernelGGL((iir_tile_state_kernel<P, false>), tiles, block, 0, stream, coef, f, y, tables, states, s);
+    hipLaunchKernelGGL(iir_tile_scan_kernel<P>, dim3(s.nchan), block, 0, stream, tables, states, state_in, s);
+    if (front)
+        hipLaunchKernelGGL((iir_apply_kernel<P, true>), tiles, block, 0, stream, coef, f, y, tables, states, s);
+    else
+        hipLaunchKernelGGL((iir_apply_kernel<P, false>), tiles, block, 0, stream, coef, f, y, tables, states, s);
     return hipGetLastError();
 }
 

@@ -147,6 +147,31 @@ def test_growing_recurrence_runs_sequentially(dsp, oracle):
     assert np.array_equal(bits(dsp.lfilter_iir(b, a, x, exact=True)), bits(ref))
 
 
+def test_many_channels_walk_their_tiles(dsp, oracle):
+    """From 1024 channels on, one workgroup walks a whole channel and carries the state itself (one pass).
+    Checked against the oracle on sampled channels and against the tile-parallel path (the same channels in
+    launches of fewer than 1024) on all of them; with a short numerator (computed inside the tail kernels) and
+    a long one (separate FIR pass), with and without incoming state."""
+    import torch
+    from scipy import signal
+
+    nchan, n = 1100, 9001
+    x = np.stack([oracle.fill_splitmix(n, dsp.SEED, c * n) for c in range(nchan)])
+    xd = torch.from_numpy(x).cuda()
+    for b, a in (signal.butter(2, 0.1), signal.butter(5, 0.3), (signal.firwin(17, 0.3), np.array([1.0, -0.6, 0.2]))):
+        bt = torch.from_numpy(np.ascontiguousarray(b)).cuda()
+        y = dsp.lfilter_iir_device(bt, a, xd)
+        for c in (0, 1, 555, nchan - 1):
+            assert scaled_err(y[c].cpu().numpy(), oracle.lfilter(b, a, x[c])) <= TOL, (a.size, c)
+        parts = torch.cat([dsp.lfilter_iir_device(bt, a, xd[lo:lo + 500].contiguous()) for lo in range(0, nchan, 500)])
+        assert scaled_err(y.cpu().numpy(), parts.cpu().numpy()) <= TOL
+        # second half given the first half's input and output history equals the whole
+        cut = 4096 + 8
+        second = dsp.lfilter_iir_device(bt, a, xd[:, cut:].contiguous(), xhist=xd[:, cut - (b.size - 1):cut].contiguous(),
+                                        yhist=y[:, cut - (a.size - 1):cut].contiguous())
+        assert scaled_err(second.cpu().numpy(), y[:, cut:].cpu().numpy()) <= TOL
+
+
 def test_device_entry_with_state(dsp, oracle):
     """dspx_lfilter_f64_dev: a stream cut into two calls, the second given the input history and the previous
     outputs, equals one call."""

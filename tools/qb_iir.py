@@ -29,6 +29,6 @@ for nchan, n, order, exact in ((4096, 1 << 20, 2, False), (4096, 1 << 20, 4, Fal
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
     print(f"{nchan} x 2^{n.bit_length() - 1}, butter({order}), {'exact (sequential)' if exact else 'block-parallel'}: "
-          f"{ms:9.3f} ms  {nchan * n / ms / 1e6:8.2f} GS/s  ({24 * nchan * n / ms / 1e9:5.2f} TB/s moved at 24 B/sample: "
-          f"x read twice, y written once)", flush=True)
+          f"{ms:9.3f} ms  {nchan * n / ms / 1e6:8.2f} GS/s  ({16 * nchan * n / ms / 1e9:5.2f} TB/s in algorithmic bytes, 16 per sample)",
+          flush=True)
     del x, y
