@@ -347,6 +347,11 @@ struct Pipeline {
     unsigned flags;
     const std::vector<Piece>* pieces;
     const Tail* tail;  // recursive part, order 0 for none
+    // download mode (d_src set): the pieces are regions of a result that already sits in device memory, row r of
+    // it destined for row row_map[r] of y (or row r when row_map is null); nothing is uploaded or launched
+    const double* d_src = nullptr;
+    size_t d_src_pitch = 0;
+    const size_t* row_map = nullptr;
     std::mutex mu;
     std::condition_variable cv;
     std::vector<unsigned char> state;  // per piece: 0 waiting, 1 on the device, 2 delivered
@@ -380,6 +385,14 @@ struct Pipeline {
         const Piece& p = (*pieces)[i];
         Slot& s = eng->slots[i % kSlots];
         const PieceGeom g(ntaps, p.len);
+        if (d_src) {
+            if (int grc = grow_slot(s, 0, g.out_pitch * p.cnt, 0)) return grc;
+            DSPX_HIP(hipMemcpy2DAsync(s.pin_out, g.out_pitch * sizeof(double), d_src + p.c * d_src_pitch + p.s0,
+                                      d_src_pitch * sizeof(double), p.len * sizeof(double), p.cnt,
+                                      hipMemcpyDeviceToHost, s.stream));
+            DSPX_HIP(hipEventRecord(s.done, s.stream));
+            return DSPX_OK;
+        }
         if (int grc = grow_slot(s, g.taps_pad + g.in_pitch * p.cnt, g.out_pitch * p.cnt,
                                 tail_workspace_bytes(*tail, p.cnt, p.len)))
             return grc;
@@ -442,7 +455,8 @@ struct Pipeline {
         const PieceGeom g(ntaps, p.len);
         DSPX_HIP(hipEventSynchronize(s.done));
         for (size_t r = 0; r < p.cnt; ++r)
-            std::memcpy(y + (p.c + r) * stride + p.s0, s.pin_out + r * g.out_pitch, p.len * sizeof(double));
+            std::memcpy(y + (row_map ? row_map[p.c + r] : p.c + r) * stride + p.s0, s.pin_out + r * g.out_pitch,
+                        p.len * sizeof(double));
         return DSPX_OK;
     }
 
@@ -465,18 +479,12 @@ struct Pipeline {
     }
 };
 
-// Filters `pieces` on `device`.  `hist0`, when non-null, holds for every channel the ntaps-1 samples that
-// precede x[0] (channel c at hist0 + c*(ntaps-1)); null means zeros.  Small calls run in the calling
+// Runs the pieces of `pl` through its engine and gives the engine back.  Small calls run in the calling
 // thread; larger ones add threads (up to `max_threads` each way) so that the copies into and out of pinned
 // staging overlap the transfers and the kernels.
-int run_device(int device, const double* taps, size_t ntaps, const double* hist0, const double* x, double* y,
-               size_t stride, const std::vector<Piece>& pieces, unsigned flags, size_t max_threads,
-               const Tail& tail = Tail{}) {
-    if (pieces.empty()) return DSPX_OK;
-    DSPX_HIP(hipSetDevice(device));
-    Engine* eng = nullptr;
-    if (int rc = acquire_engine(device, &eng)) return rc;
-    Pipeline pl(device, eng, taps, hist0, x, y, ntaps, stride, flags, &pieces, &tail);
+int run_pipeline(Pipeline& pl, size_t max_threads) {
+    const std::vector<Piece>& pieces = *pl.pieces;
+    Engine* eng = pl.eng;
     auto body = [&]() -> int {
         if (pieces.size() <= 2) {
             for (size_t i = 0; i < pieces.size(); ++i)
@@ -488,13 +496,14 @@ int run_device(int device, const double* taps, size_t ntaps, const double* hist0
         // copy threads per direction: measured on an MI355X host, 1 / 2 / 3 threads move 3.2 / 3.7 / 4.1 G
         // samples/s end to end; more than 3 gain little and take cores from the caller
         size_t nthreads = std::min<size_t>(max_threads, pieces.size() >= 32 ? 3 : pieces.size() >= 8 ? 2 : 1);
-        if (tail.order)  // pieces that continue a channel must be issued in order
+        if (pl.tail->order)  // pieces that continue a channel must be issued in order
             for (const Piece& p : pieces)
                 if (p.s0 > 0) nthreads = 1;
+        const size_t producers = pl.d_src ? 1 : nthreads;  // issuing a download costs the host nothing
         std::vector<std::thread> workers;
         for (size_t k = 0; k < nthreads; ++k) workers.emplace_back([&pl, k, nthreads] { pl.consumer(k, nthreads); });
-        for (size_t k = 1; k < nthreads; ++k) workers.emplace_back([&pl, k, nthreads] { pl.producer(k, nthreads); });
-        pl.producer(0, nthreads);
+        for (size_t k = 1; k < producers; ++k) workers.emplace_back([&pl, k, producers] { pl.producer(k, producers); });
+        pl.producer(0, producers);
         for (auto& w : workers) w.join();
         if (pl.rc != DSPX_OK) g_last_error = pl.msg;
         return pl.rc;
@@ -502,11 +511,26 @@ int run_device(int device, const double* taps, size_t ntaps, const double* hist0
     const int rc = body();
     const std::string keep = g_last_error;
     bool healthy = rc == DSPX_OK;
-    if (!healthy)  // leave nothing queued on streams that outlive this call
+    if (!healthy) {  // leave nothing queued on streams that outlive this call
+        healthy = true;
         for (auto& s : eng->slots) healthy = (hipStreamSynchronize(s.stream) == hipSuccess) && healthy;
-    release_engine(eng, rc == DSPX_OK || healthy);
+    }
+    release_engine(eng, healthy);
     if (rc != DSPX_OK) g_last_error = keep;
     return rc;
+}
+
+// Filters `pieces` on `device`.  `hist0`, when non-null, holds for every channel the ntaps-1 samples that
+// precede x[0] (channel c at hist0 + c*(ntaps-1)); null means zeros.
+int run_device(int device, const double* taps, size_t ntaps, const double* hist0, const double* x, double* y,
+               size_t stride, const std::vector<Piece>& pieces, unsigned flags, size_t max_threads,
+               const Tail& tail = Tail{}) {
+    if (pieces.empty()) return DSPX_OK;
+    DSPX_HIP(hipSetDevice(device));
+    Engine* eng = nullptr;
+    if (int rc = acquire_engine(device, &eng)) return rc;
+    Pipeline pl(device, eng, taps, hist0, x, y, ntaps, stride, flags, &pieces, &tail);
+    return run_pipeline(pl, max_threads);
 }
 
 int host_path(const double* taps, size_t ntaps, const double* hist0, const double* x, double* y, size_t nchan,
@@ -544,6 +568,24 @@ int host_path(const double* taps, size_t ntaps, const double* hist0, const doubl
 }
 
 }  // namespace
+
+namespace dspx {
+
+int download_rows(int device, const double* d_src, size_t src_pitch, size_t rows, size_t n, double* dst, size_t dst_stride,
+                  const size_t* row_map) {
+    if (rows == 0 || n == 0) return DSPX_OK;
+    DSPX_HIP(hipSetDevice(device));
+    std::vector<Piece> pieces;
+    cut_pieces(0, rows, 0, n, pieces);
+    Engine* eng = nullptr;
+    if (int rc = acquire_engine(device, &eng)) return rc;
+    const Tail none;
+    Pipeline pl(device, eng, nullptr, nullptr, nullptr, dst, 0, dst_stride, 0, &pieces, &none);
+    pl.d_src = d_src, pl.d_src_pitch = src_pitch, pl.row_map = row_map;
+    return run_pipeline(pl, 3);
+}
+
+}  // namespace dspx
 
 extern "C" {
 

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <cstddef>
 #include <cstdint>
 #include <string>
 
@@ -36,6 +37,12 @@ inline bool use_matrix_pipe(unsigned flags, size_t ntaps) {
 // workgroups resident and wins below kMatrixPipeWideTaps; above, the 4096-output tile reads less LDS per product.
 constexpr size_t kMatrixPipeWideTaps = 224;
 inline int matrix_row_blocks(size_t ntaps) { return ntaps >= kMatrixPipeWideTaps ? 4 : 2; }
+
+// Copies `rows` rows of `n` doubles from device memory (row r at d_src + r*src_pitch) into host memory (row r
+// to dst + (row_map ? row_map[r] : r)*dst_stride) through the pinned staging pipeline of the host-pointer
+// entry points (defined in dspx_capi.hip).
+int download_rows(int device, const double* d_src, size_t src_pitch, size_t rows, size_t n, double* dst,
+                  size_t dst_stride, const size_t* row_map);
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 

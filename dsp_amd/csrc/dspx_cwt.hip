@@ -218,9 +218,7 @@ int run_cwt_device(int device, const Tables& t, const double* psi, const std::ve
         DSPX_HIP(hipMemcpy(d_sig, signal, n * sizeof(double), hipMemcpyHostToDevice));
         if (int rc = apply_bank(bank, d_sig, n, d_res, pitch, flags, nullptr)) return rc;
         DSPX_HIP(hipDeviceSynchronize());
-        for (size_t i = 0; i < pick.size(); ++i)
-            DSPX_HIP(hipMemcpy(result + pick[i] * n, d_res + i * pitch, n * sizeof(double), hipMemcpyDeviceToHost));
-        return DSPX_OK;
+        return dspx::download_rows(device, d_res, pitch, pick.size(), n, result, n, pick.data());
     };
     const int rc = body();
     const std::string keep = dspx::g_last_error;

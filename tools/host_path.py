@@ -29,3 +29,16 @@ for lg in [int(a) for a in sys.argv[1:]] or [20, 24, 27]:
         reuse = min(reuse, time.perf_counter() - t0)
     print(f"lfilter 255 taps, n=2^{lg}: fresh output {best * 1e3:9.2f} ms {n / best / 1e9:6.3f} GS/s | reused output "
           f"{reuse * 1e3:9.2f} ms {n / reuse / 1e9:6.3f} GS/s ({16 * n / reuse / 1e9:5.1f} GB/s both directions)", flush=True)
+
+# the wavelet bank from host memory: 65 scales, result 65 x n doubles brought back through pinned staging
+psi, wx = dsp_amd.integrate_wavelet(10)
+scales = np.arange(1, 66, dtype=np.float64)
+for lg in (16, 20, 22):
+    sig = rng.uniform(-1, 1, 1 << lg)
+    dsp_amd.cwt(sig[:4096], scales, psi, wx)
+    best = 1e9
+    for _ in range(3):
+        t0 = time.perf_counter()
+        out = dsp_amd.cwt(sig, scales, psi, wx)
+        best = min(best, time.perf_counter() - t0)
+    print(f"cwt 65 scales, n=2^{lg}: {best * 1e3:9.2f} ms  ({out.nbytes / best / 1e9:5.1f} GB/s of result)", flush=True)
