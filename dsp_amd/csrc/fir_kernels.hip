@@ -3,8 +3,10 @@
 // Computes y[i] = sum_j taps[j] * x[i-j] with taps ascending per output, i.e. the
 // inner loop of the reference lfilter (dsp.hpp:356-365) for a denominator of size 1,
 // with the samples before x[0] taken as zero (or from an explicit history buffer).
+// Two kernels: fir_f64_kernel on the vector pipe (described here) and fir_f64_mfma_kernel on
+// the matrix pipe (described where it starts, further down).
 //
-// Work decomposition
+// Work decomposition (vector pipe)
 //   * one workgroup (256 threads = 4 waves) produces a tile of 2048 consecutive
 //     outputs of one channel; thread t owns outputs 8t .. 8t+7 of the tile;
 //   * taps are consumed in stages of at most 256; per stage the workgroup copies the
@@ -29,10 +31,7 @@ namespace dspx {
 
 namespace {
 
-#ifndef DSPX_BLOCK
-#define DSPX_BLOCK 256
-#endif
-constexpr int kBlock = DSPX_BLOCK;        // threads per workgroup
+constexpr int kBlock = 256;               // threads per workgroup
 constexpr int kR = 8;                     // outputs per thread
 constexpr int kGroup = 16;                // taps per unrolled group
 constexpr int kWin = kGroup + kR;         // samples a group reads per thread (23 needed, 24 loaded)
@@ -285,13 +284,13 @@ __global__ __launch_bounds__(kBlock) void fir_f64_kernel(const double* __restric
 // ---------------------------------------------------------------------------------------------
 // Toeplitz-block variant on the FP64 matrix pipe (v_mfma_f64_16x16x4_f64).
 //
-// One wave computes 16 segments (matrix columns n) of 64 consecutive outputs each, as four
-// 16-row blocks per segment.  For a tap offset d (a multiple of 4) the product
+// One wave computes 16 segments (matrix columns n) of 16*OB consecutive outputs each, as OB
+// 16-row blocks per segment (OB = 4 or 2).  For a tap offset d (a multiple of 4) the product
 //     D[m][n] += sum_k A[m][k] * B[k][n],   A[m][k] = taps[d + m - k],   B[k][n] = x[seg(n) + i0 - d + k]
 // adds, to output i0 + m of every segment, the four taps d+m-3 .. d+m.  A is the same 16x4
 // Toeplitz block for every segment and every i0 (one LDS read per step from a zero-padded copy
 // of the stage's taps); B is four consecutive input samples of each segment (one LDS read per
-// product).  A filter of N taps takes floor((N+2)/4) + 4 steps: the band is about N + 16 columns
+// product).  A filter of N taps takes floor((N+2)/4) + 4 steps: the band is N + 15 columns
 // wide instead of N, so 6 % of the multiplies are by zero at 255 taps and 0.4 % at 4095.
 //
 // Why it exists: on random data the chip holds ~2.39 GHz while issuing these products but only
