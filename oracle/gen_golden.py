@@ -97,6 +97,15 @@ def outputs() -> dict:
     z["short_y_4095"] = ref.lfilter_scalar_den(z["taps_4095_0p1"], 1.0, xs)
     z["iir_a"] = np.array([1.0, -0.5, 0.25])
     z["iir_y"] = ref.lfilter(z["taps_100_0p5"][:7], z["iir_a"], xs)
+    # the recursive branch over more than two tiles of the GPU kernels: a 4-pole low-pass whose a[0] is not 1
+    # (the reference never reads it, dsp.hpp:366), and a resonator
+    xs = orc.fill_splitmix(9000, SEED, 777)
+    z["iir4_b"] = np.array([0.0048, 0.0193, 0.0289, 0.0193, 0.0048])
+    z["iir4_a"] = np.array([3.0, -2.3695, 2.3140, -1.0547, 0.1874])
+    z["iir4_y"] = ref.lfilter(z["iir4_b"], z["iir4_a"], xs)
+    z["iir2_b"] = np.array([1.0, 0.5, 0.25])
+    z["iir2_a"] = np.array([1.0, 0.0, 0.81])
+    z["iir2_y"] = ref.lfilter(z["iir2_b"], z["iir2_a"], xs)
     # wavelet bank
     psi, wx = ref.integrate_wavelet(10)
     z["morlet10_psi"], z["morlet10_x"] = psi, wx

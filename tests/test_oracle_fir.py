@@ -85,6 +85,9 @@ def test_ragged_short_and_iir_bit_exact(oracle, golden):
     assert np.array_equal(bits(oracle.lfilter(golden["taps_255_0p25"], [1.0], x[:777])), bits(golden["ragged_y_255"]))
     assert np.array_equal(bits(oracle.lfilter(golden["taps_4095_0p1"], [1.0], x)), bits(golden["short_y_4095"]))
     assert np.array_equal(bits(oracle.lfilter(golden["taps_100_0p5"][:7], golden["iir_a"], x)), bits(golden["iir_y"]))
+    x = oracle.fill_splitmix(9000, SEED, 777)
+    for k in ("iir4", "iir2"):
+        assert np.array_equal(bits(oracle.lfilter(golden[k + "_b"], golden[k + "_a"], x)), bits(golden[k + "_y"]))
 
 
 def test_edge_cases(oracle):
