@@ -87,7 +87,7 @@ DSPX_API int dspx_fir_f64_batched(const double* taps, size_t ntaps, const double
 /* Same contract, sharded over the first `ngpus` devices (0 = all): contiguous channel
  * ranges when nchan >= ngpus, otherwise contiguous segments of each channel with the
  * preceding ntaps-1 input samples as history.  No inter-device exchange; results are
- * bit-identical for every ngpus.  One host thread and stream per device. */
+ * bit-identical for every ngpus.  One staging pipeline per device (pinned buffers, a few copy threads). */
 DSPX_API int dspx_fir_f64_multi(const double* taps, size_t ntaps, const double* x, double* y, size_t nchan, size_t n,
                        size_t stride, int ngpus, unsigned flags);
 
