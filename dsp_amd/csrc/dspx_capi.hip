@@ -42,7 +42,7 @@ using dspx::aligned16;
 using dspx::fail;
 using dspx::g_last_error;
 
-constexpr unsigned long long kMaxGrid = 0x7fffffffull;  // workgroups per launch
+using dspx::kMaxGrid;
 
 bool ranges_overlap(const void* a, size_t abytes, const void* b, size_t bbytes) {
     const uintptr_t a0 = reinterpret_cast<uintptr_t>(a), b0 = reinterpret_cast<uintptr_t>(b);

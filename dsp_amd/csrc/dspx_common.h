@@ -15,6 +15,10 @@ extern thread_local std::string g_last_error;
 // Records a thread-local message and returns `code`.
 int fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
 
+// Workgroups per launch: HIP launches nothing (and reports nothing) when grid * block reaches 2^32 threads,
+// so with 256-thread workgroups a grid stays below 2^24.
+constexpr unsigned long long kMaxGrid = (1ull << 24) - 1;
+
 // Taps from which the FP64 matrix pipe is faster than the vector pipe (measured on MI355X).
 constexpr size_t kMatrixPipeMinTaps = 96;
 

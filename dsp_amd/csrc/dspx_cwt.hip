@@ -179,7 +179,7 @@ int apply_bank(const dspx_cwt_bank* bank, const double* d_signal, size_t n, doub
         const size_t stride = (size_t)(mfma ? dspx::fir_mfma_bank_stride(ob) : dspx::fir_bank_stride());
         const size_t tiles_per_row = (n + stride - 1) / stride;
         const size_t run = (tiles_per_row + 7) / 8;  // tiles per row and XCD
-        const size_t max_rows = 0x7fffffffull / (8 * run);
+        const size_t max_rows = dspx::kMaxGrid / (8 * run);
         if (max_rows == 0) return fail(DSPX_ERR_INVALID, "signal too long for one launch: %zu", n);
         for (size_t r0 = 0; r0 < count; r0 += max_rows) {
             const size_t nr = std::min(max_rows, count - r0);

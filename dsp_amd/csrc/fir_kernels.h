@@ -11,7 +11,7 @@ struct FirShape {
     long long n;                     // samples per channel
     unsigned long long div_magic;    // tile_id / tiles_per_chan == (tile_id * div_magic) >> div_shift
     unsigned div_shift;
-    unsigned total_tiles;            // nchan * tiles_per_chan  (< 2^31)
+    unsigned total_tiles;            // nchan * tiles_per_chan  (< 2^24: grid * 256 threads must stay below 2^32)
     unsigned tiles_per_chan;         // ceil(n / fir_tile())
     int ntaps;
 };

@@ -32,6 +32,8 @@ namespace dspx {
 namespace {
 
 constexpr int kBlock = 256;               // threads per workgroup
+// A launch of 2^32 or more threads is dropped by the runtime without an error: refuse it here.
+constexpr bool grid_fits(unsigned workgroups) { return (unsigned long long)workgroups * kBlock < (1ull << 32); }
 constexpr int kR = 8;                     // outputs per thread
 constexpr int kGroup = 16;                // taps per unrolled group
 constexpr int kWin = kGroup + kR;         // samples a group reads per thread (23 needed, 24 loaded)
@@ -589,6 +591,7 @@ static void launch_mfma_variant(const double* taps, const double* x, const doubl
 hipError_t launch_fir_mfma_f64(const double* taps, const double* x, const double* hist, double* y,
                                const FirShape& shape, int row_blocks, bool vec2, hipStream_t stream) {
     if (shape.total_tiles == 0) return hipSuccess;
+    if (!grid_fits(shape.total_tiles)) return hipErrorInvalidConfiguration;
     if (row_blocks == 2)
         launch_mfma_variant<2, false>(taps, x, hist, y, nullptr, shape, vec2, stream);
     else
@@ -599,6 +602,7 @@ hipError_t launch_fir_mfma_f64(const double* taps, const double* x, const double
 hipError_t launch_fir_mfma_bank_f64(const double* taps, const BankRow* bank, const double* x, double* y,
                                     const FirShape& shape, int row_blocks, bool vec2, hipStream_t stream) {
     if (shape.total_tiles == 0) return hipSuccess;
+    if (!grid_fits(shape.total_tiles)) return hipErrorInvalidConfiguration;
     if (row_blocks == 2)
         launch_mfma_variant<2, true>(taps, x, nullptr, y, bank, shape, vec2, stream);
     else
@@ -611,6 +615,7 @@ int fir_bank_stride() { return kBankStride; }
 hipError_t launch_fir_f64(const double* taps, const double* x, const double* hist, double* y, const FirShape& shape,
                           bool exact, bool vec2, hipStream_t stream) {
     if (shape.total_tiles == 0) return hipSuccess;
+    if (!grid_fits(shape.total_tiles)) return hipErrorInvalidConfiguration;
     const dim3 grid(shape.total_tiles), block(kBlock);
     const BankRow* none = nullptr;
     if (exact) {
@@ -630,6 +635,7 @@ hipError_t launch_fir_f64(const double* taps, const double* x, const double* his
 hipError_t launch_fir_bank_f64(const double* taps, const BankRow* bank, const double* x, double* y,
                                const FirShape& shape, bool exact, bool vec2, hipStream_t stream) {
     if (shape.total_tiles == 0) return hipSuccess;
+    if (!grid_fits(shape.total_tiles)) return hipErrorInvalidConfiguration;
     const dim3 grid(shape.total_tiles), block(kBlock);  // rows * 8 * ceil(tiles_per_chan / 8)
     const double* none = nullptr;
     if (exact) {

@@ -526,6 +526,8 @@ bool iir_tables_usable(const double* a, int order) {
 hipError_t launch_iir_scan(const IirCoef& coef, int order, double* y, const double* state_in, const IirShape& shape,
                            const IirFront* front, void* work, hipStream_t stream) {
     if (shape.nchan == 0 || shape.n == 0) return hipSuccess;
+    // a launch of 2^32 or more threads is dropped by the runtime without an error: refuse it here
+    if ((unsigned long long)shape.nchan * shape.tiles_per_chan * kBlock >= (1ull << 32)) return hipErrorInvalidConfiguration;
     IirTables* tables = static_cast<IirTables*>(work);
     double* states = reinterpret_cast<double*>(static_cast<char*>(work) + kTablesBytes);
 #define DSPX_IIR_SCAN(P) scan_path<P>(coef, y, state_in, shape, front, tables, states, stream)

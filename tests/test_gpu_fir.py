@@ -234,6 +234,21 @@ def test_host_path_pipeline_shapes(dsp, oracle):
     assert np.array_equal(bits(dsp.lfilter(b31, xs[0][:5000], exact=True)), bits(out[0][:5000]))
 
 
+def test_more_workgroups_than_one_launch_holds(dsp, torch):
+    """2^24 + 5 one-sample channels need more workgroups than one launch can have (a launch of 2^32 threads or
+    more is dropped by the runtime without an error): the call is split, on either pipe."""
+    nchan = (1 << 24) + 5
+    x = torch.empty((nchan, 1), dtype=torch.float64, device="cuda")
+    dsp.fill_splitmix(x, dsp.SEED, 0)
+    taps = torch.tensor([0.5, 0.25, 0.125], dtype=torch.float64, device="cuda")
+    for pipe in (False, True):
+        y = torch.full_like(x, 7.0)
+        dsp.fir_device(taps, x, out=y, mfma=pipe)
+        assert torch.equal(y, 0.5 * x), pipe
+    y = dsp.lfilter_iir_device(taps, [1.0, -0.5], x)       # the recursive tail splits the same way
+    assert torch.equal(y, 0.5 * x)
+
+
 def test_splitmix_fill_and_checksum_match_oracle(dsp, oracle, torch):
     n = 100003
     t = torch.empty(n, dtype=torch.float64, device="cuda")
