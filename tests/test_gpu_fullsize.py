@@ -114,6 +114,24 @@ def test_long_stream_segment_sharding(env, oracle, golden, numtaps, cutoff, log2
         assert dsp.checksum(y2, 0) == ref_sum, pipe
 
 
+def test_stream_longer_than_2e32_samples(env, oracle):
+    """Sample indices beyond 32 bits: one stream of 2^32 + 5 samples (32 GiB in, 32 GiB out), windows around
+    2^31, 2^32 and the ragged end against the oracle, on both pipes."""
+    torch, dsp = env
+    n = (1 << 32) + 5
+    taps_h = dsp.firwin(31, 0.3)
+    taps = torch.from_numpy(taps_h).cuda()
+    x = torch.empty(n, dtype=torch.float64, device="cuda")
+    y = torch.empty_like(x)
+    dsp.fill_splitmix(x, dsp.SEED, 0)
+    for pipe in (None, True):
+        y.zero_()
+        dsp.fir_device(taps, x, out=y, mfma=pipe)
+        for start in (0, (1 << 31) - 2048, (1 << 32) - 4096, n - 4096):
+            check_window(dsp, oracle, taps_h, y, 0, start)
+    del x, y
+
+
 def test_shift_invariance_across_tiles(env):
     """Delaying the input by k samples delays the output by k samples, bit for bit, for delays
     that move every sample to a different place in its tile."""
