@@ -17,7 +17,8 @@
 // reference loop (dsp.hpp:366-368) on the GPU as well.
 // There is no CPU filtering path in this header: a failing GPU call throws
 // std::runtime_error, and inputs the GPU path does not cover are rejected
-//   - at compile time when T or a container's value_type is not double,
+//   - at compile time when T is not double, or when the reference would form the products
+//     numerators * x in a type other than double (e.g. float taps over float samples),
 //   - with std::invalid_argument when the denominator has more than nine
 //     coefficients.
 //
@@ -186,8 +187,8 @@ template <typename T = double> struct lfilter_ctx_t { std::vector<T> result; };
 
 namespace detail {
 
-// Contiguous view of a container of doubles; copies only when the container is not
-// contiguous in memory (e.g. std::deque).
+// Contiguous view of a container as doubles; copies (converting each element) only when the
+// container is not a contiguous array of double (e.g. std::deque<double>, std::vector<float>).
 template <typename C> class double_view {
   public:
     explicit double_view(const C& c) : size_(c.size()) {
@@ -217,10 +218,17 @@ template <typename T = double, typename Container_1, typename Container_2, typen
              indexable_of<Container_3, T>
 void lfilter(lfilter_ctx_t<T>& ctx, const Container_1& numerators, const Container_2& denominators,
              const Container_3& x) {
-    static_assert(std::is_same_v<T, double> && std::is_same_v<typename Container_1::value_type, double> &&
-                    std::is_same_v<typename Container_2::value_type, double> &&
-                    std::is_same_v<typename Container_3::value_type, double>,
-                  "dsp::lfilter (MI355X): only T = double over containers of double is implemented");
+    // The reference multiplies numerators[j] * x[i-j] and denominators[j] * y[i-j] in the type the operands
+    // promote to and only then converts to T (dsp.hpp:363, 367).  Whenever those products are formed in double
+    // (at least one of numerators / x holds double, nothing holds long double), converting the other operand to
+    // double first -- which is all that happens to such containers here -- gives the same values.
+    using V1 = typename Container_1::value_type;
+    using V2 = typename Container_2::value_type;
+    using V3 = typename Container_3::value_type;
+    static_assert(std::is_same_v<T, double> && std::is_same_v<decltype(std::declval<V1>() * std::declval<V3>()), double> &&
+                    std::is_same_v<decltype(std::declval<V2>() * std::declval<double>()), double>,
+                  "dsp::lfilter (MI355X): T must be double and the products numerators * x and denominators * y "
+                  "must be formed in double (e.g. double taps over float or integer samples)");
     const std::size_t n = x.size();
     if (ctx.result.size() != n) [[unlikely]] ctx.result.resize(n);
     if (n == 0) return;

@@ -135,6 +135,25 @@ int main(int argc, char** argv) {
         // non-contiguous container, std::array taps
         std::deque<double> dq(x.begin(), x.end());
         CHECK(lfilter<double>(w, 1.0, dq) == a);
+        // samples or taps of another arithmetic type: the reference forms each product in double after
+        // promoting the operand (dsp.hpp:363), which is what converting the container first does
+        {
+            std::vector<float> xf(x.size());
+            std::vector<double> xf_as_double(x.size());
+            std::vector<int> xi(x.size());
+            std::vector<double> xi_as_double(x.size());
+            for (size_t i = 0; i < x.size(); ++i) {
+                xf[i] = static_cast<float>(x[i]);
+                xf_as_double[i] = static_cast<double>(xf[i]);
+                xi[i] = static_cast<int>(1000.0 * x[i]);
+                xi_as_double[i] = static_cast<double>(xi[i]);
+            }
+            CHECK(lfilter<double>(w, 1.0, xf) == lfilter<double>(w, 1.0, xf_as_double));
+            CHECK(lfilter<double>(w, 1.0, xi) == lfilter<double>(w, 1.0, xi_as_double));
+            std::vector<float> wf(w.begin(), w.end());
+            std::vector<double> wf_as_double(wf.begin(), wf.end());
+            CHECK(lfilter<double>(wf, 1.0, x) == lfilter<double>(wf_as_double, 1.0, x));
+        }
         // empty input -> empty output, empty numerators -> zeros
         CHECK(lfilter<double>(w, 1.0, std::vector<double>{}).empty());
         auto z = lfilter<double>(std::vector<double>{}, 1.0, x);
