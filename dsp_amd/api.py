@@ -71,16 +71,20 @@ def lfilter(b, x, exact: bool = False, mfma=None, out=None) -> np.ndarray:
     return y
 
 
-def lfilter_iir(b, a, x, exact: bool = False, mfma=None) -> np.ndarray:
+def lfilter_iir(b, a, x, exact: bool = False, mfma=None, ngpus=None) -> np.ndarray:
     """dsp::lfilter(b, a, x) with a recursive part (dsp.hpp:342-371) for host arrays: 1-D x, or 2-D
-    (channels, samples).  a[0] is never read."""
+    (channels, samples).  a[0] is never read.  ngpus: shard the channels over that many devices (0 = all)."""
     b, a, x = _np_f64(b), _np_f64(np.atleast_1d(a)), _np_f64(x)
     x2 = x.reshape(1, -1) if x.ndim == 1 else x
     if x2.ndim != 2:
         raise ValueError("x must be 1-D or 2-D")
     y = np.empty_like(x2)
-    check(lib().dspx_lfilter_f64(b.ctypes.data, b.size, a.ctypes.data, a.size, x2.ctypes.data, y.ctypes.data,
-                                 x2.shape[0], x2.shape[1], x2.shape[1], _flags(exact, mfma)))
+    if ngpus is None:
+        check(lib().dspx_lfilter_f64(b.ctypes.data, b.size, a.ctypes.data, a.size, x2.ctypes.data, y.ctypes.data,
+                                     x2.shape[0], x2.shape[1], x2.shape[1], _flags(exact, mfma)))
+    else:
+        check(lib().dspx_lfilter_f64_multi(b.ctypes.data, b.size, a.ctypes.data, a.size, x2.ctypes.data, y.ctypes.data,
+                                           x2.shape[0], x2.shape[1], x2.shape[1], int(ngpus), _flags(exact, mfma)))
     return y.reshape(x.shape)
 
 

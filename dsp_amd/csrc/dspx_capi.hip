@@ -549,15 +549,17 @@ int host_path(const double* taps, size_t ntaps, const double* hist0, const doubl
         cut_pieces(0, nchan, 0, n, pieces);
         return run_device(cur, taps, ntaps, hist0, x, y, stride, pieces, flags, 3, tail);
     }
-    const int G = ngpus == 0 ? ndev : ngpus;
+    int G = ngpus == 0 ? ndev : ngpus;
     if (G > ndev) return fail(DSPX_ERR_INVALID, "ngpus (%d) exceeds visible devices (%d)", G, ndev);
+    // a recursive filter's state is a serial dependence along a channel: such filters shard by channels only
+    if (tail.order && nchan < (size_t)G) G = (int)nchan;
     const std::vector<std::vector<Piece>> plan = make_plan(nchan, n, G);
     std::vector<int> rcs(G, DSPX_OK);
     std::vector<std::string> msgs(G);
     std::vector<std::thread> workers;
     for (int g = 0; g < G; ++g)
         workers.emplace_back([&, g] {
-            rcs[g] = run_device(g, taps, ntaps, hist0, x, y, stride, plan[g], flags, G > 2 ? 1 : 2);
+            rcs[g] = run_device(g, taps, ntaps, hist0, x, y, stride, plan[g], flags, G > 2 ? 1 : 2, tail);
             if (rcs[g] != DSPX_OK) msgs[g] = g_last_error;
         });
     for (auto& w : workers) w.join();
@@ -692,6 +694,15 @@ int dspx_lfilter_f64(const double* b, size_t nb, const double* a, size_t na, con
     Tail tail;
     if (int rc = make_tail(a, na, flags, tail)) return rc;
     return host_path(b, nb, nullptr, x, y, nchan, n, stride, -1, flags, tail);
+}
+
+int dspx_lfilter_f64_multi(const double* b, size_t nb, const double* a, size_t na, const double* x, double* y,
+                           size_t nchan, size_t n, size_t stride, int ngpus, unsigned flags) {
+    if (ngpus < 0) return fail(DSPX_ERR_INVALID, "ngpus must be >= 0");
+    if (int rc = dspx::check_flags(flags)) return rc;
+    Tail tail;
+    if (int rc = make_tail(a, na, flags, tail)) return rc;
+    return host_path(b, nb, nullptr, x, y, nchan, n, stride, ngpus, flags, tail);
 }
 
 size_t dspx_lfilter_workspace_bytes(size_t na, size_t nchan, size_t n) {

@@ -113,6 +113,12 @@ DSPX_API int dspx_fir_f64_stream(const double* taps, size_t ntaps, double* hist,
 DSPX_API int dspx_lfilter_f64(const double* b, size_t nb, const double* a, size_t na, const double* x, double* y,
                               size_t nchan, size_t n, size_t stride, unsigned flags);
 
+/* Same contract, sharded over the first `ngpus` devices (0 = all) by contiguous channel ranges.  With a
+ * recursive part (na > 1) a channel is never split across devices (its state is a serial dependence), so at
+ * most nchan devices work; without one this is dspx_fir_f64_multi. */
+DSPX_API int dspx_lfilter_f64_multi(const double* b, size_t nb, const double* a, size_t na, const double* x, double* y,
+                                    size_t nchan, size_t n, size_t stride, int ngpus, unsigned flags);
+
 /* Device-resident form: dspx_fir_f64_dev followed by the recursive tail, in place on d_y.  `a` is a HOST
  * pointer (na coefficients, read during the call).  d_xhist as d_hist of dspx_fir_f64_dev; d_yhist (optional):
  * per channel the na-1 outputs that precede y[0], oldest first (channel c at d_yhist + c*yhist_stride).
