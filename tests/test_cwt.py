@@ -134,9 +134,10 @@ def test_seeded_cwt_vs_reference_output(dsp, oracle, golden):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n", [1, 2, 7, 100, 2039, 2040, 2041, 2048, 4081, 10000])
+@pytest.mark.parametrize("n", [1, 2, 7, 100, 2039, 2040, 2041, 2045, 2046, 2047, 2048, 4081, 4093, 4094, 4095, 8189, 10000])
 def test_cwt_lengths_vs_oracle(dsp, oracle, golden, n):
-    """Signals shorter than the kernels, and lengths around the 2040-output tile stride."""
+    """Signals shorter than the kernels, and lengths around the tile strides of bank mode (2040 on the vector
+    pipe, 2046 and 4094 on the matrix pipe)."""
     psi, wx = golden["morlet10_psi"], golden["morlet10_x"]
     sig = oracle.fill_splitmix(n, dsp.SEED, n)
     scales = [0.7, 1.0, 3.3, 16.0, 65.0]

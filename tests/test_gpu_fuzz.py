@@ -122,3 +122,25 @@ def test_recursive_device_entry_fuzz(env, oracle):
             assert np.array_equal(bits(got), bits(ref)), tag
         else:
             assert scaled_err(got, ref) <= 1e-11, tag    # random pole sets: the loop above is itself only ~1e-13 accurate
+
+
+def test_wavelet_bank_fuzz(env, oracle, golden):
+    """Random scale sets (fractional, unsorted, repeated lengths) and signal lengths: every row against the oracle."""
+    torch, dsp = env
+    rng = np.random.default_rng(99)
+    psi, wx = golden["morlet10_psi"], golden["morlet10_x"]
+    for case in range(40):
+        n = int(rng.choice([2, 3, 17, 500, 2046, 4094, 4095, 7000, 12289]))
+        scales = np.round(rng.uniform(0.3, 70.0, int(rng.integers(1, 9))), int(rng.integers(0, 3)))
+        scales = scales[scales >= 0.25]
+        if scales.size == 0:
+            continue
+        sig = rng.uniform(-1, 1, n)
+        try:
+            ref = oracle.cwt(sig, np.sort(scales), psi, wx)
+        except (ValueError, RuntimeError):
+            continue                                        # a scale the reference rejects for this length
+        got = dsp.cwt(sig, scales, psi, wx, mfma=[None, True, False][case % 3])
+        assert got.shape == ref.shape
+        for r in range(ref.shape[0]):
+            assert scaled_err(got[r], ref[r]) <= 1e-11, (case, n, np.sort(scales)[r])
