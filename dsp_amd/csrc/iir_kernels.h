@@ -11,6 +11,8 @@ namespace dspx {
 constexpr int kIirMaxOrder = 8;   // P of the kernels below (na <= 9)
 constexpr int kIirLevels = 8;     // log2 of the 256 lanes (or tiles) one scan covers
 constexpr int kIirTile = 4096;    // samples per workgroup: 256 lanes x 16 consecutive samples
+constexpr int kIirTileRun = 16;   // tiles a lane of the tile-state scan walks by itself
+constexpr int kIirTileLevels = kIirLevels + 4;  // powers of A^4096 kept: 2^0 .. 2^11 (2^4 = one lane's run)
 
 // Coefficients by value (kernel argument): a[j-1] = a_j.
 struct IirCoef {
@@ -18,7 +20,8 @@ struct IirCoef {
 };
 
 // Powers of the companion matrix A of the recurrence (state = the P most recent outputs, newest first):
-// lane[d] = (A^16)^(2^d) carries a state across 2^d lanes, tile[d] = (A^4096)^(2^d) across 2^d tiles.
+// lane[d] = (A^16)^(2^d) carries a state across 2^d lanes, tile[d] = (A^4096)^(2^d) across 2^d tiles
+// (tile[4 + d] across 2^d lanes of the tile-state scan, whose lanes walk 16 tiles each).
 // Each entry is an unevaluated sum hi + lo of two doubles: a state of a narrow-band filter is a smooth
 // sequence, and a matrix power applied to it cancels terms thousands of times larger than the result, so
 // the entries and the dot products carry about twice the precision of a double.
@@ -28,7 +31,7 @@ struct IirMatrix {
 };
 struct IirTables {
     IirMatrix lane[kIirLevels];
-    IirMatrix tile[kIirLevels];
+    IirMatrix tile[kIirTileLevels];
 };
 
 // The FIR part, when the tail kernels compute it on the fly from x instead of reading it from y (short

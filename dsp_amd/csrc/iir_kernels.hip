@@ -6,7 +6,7 @@
 // samples, a workgroup a tile of 4096:
 //   1. iir_tile_state_kernel: every lane runs its 16 samples from zero state; a Kogge-Stone scan over the
 //      256 lanes with the constant matrices (A^16)^(2^d) gives the state the tile reaches from zero.
-//   2. iir_tile_scan_kernel: one workgroup per channel scans those tile states with (A^4096)^(2^d), 256 tiles
+//   2. iir_tile_scan_kernel: one workgroup per channel scans those tile states with (A^4096)^(2^d), 4096 tiles
 //      per pass, and leaves in their place the state every tile starts from.
 //   3. iir_apply_kernel: as 1., with the tile's true starting state folded into lane 0; every lane then knows
 //      the state it starts from and runs its 16 samples again from it, which yields the outputs.
@@ -226,9 +226,9 @@ __global__ __launch_bounds__(64) void iir_tables_kernel(IirCoef coef, int order,
         e = square();
     }
     // e = (A^16)^256 = A^4096
-    for (int d = 0; d < kIirLevels; ++d) {
+    for (int d = 0; d < kIirTileLevels; ++d) {
         out->tile[d].hi[r][c] = e.hi, out->tile[d].lo[r][c] = e.lo;
-        if (d + 1 < kIirLevels) e = square();
+        if (d + 1 < kIirTileLevels) e = square();
     }
 }
 
@@ -259,40 +259,62 @@ __global__ __launch_bounds__(kBlock) void iir_tile_state_kernel(IirCoef coef, Ii
 }
 
 // One workgroup per channel.  On entry states[chan][t] is the state tile t reaches from zero; on exit it is
-// the state tile t starts from.
+// the state tile t starts from.  A lane walks 16 consecutive tiles by itself (state <- A^4096 * state + tile
+// state), the 256 lane results are joined by the same scan as the lanes of a tile, and the lane walks its
+// tiles again from the state it really starts from: 4096 tiles per pass.
 template <int P>
 __global__ __launch_bounds__(kBlock) void iir_tile_scan_kernel(const IirTables* __restrict__ tables,
                                                                double* __restrict__ states,
                                                                const double* __restrict__ state_in, IirShape s) {
+    static_assert((1 << 4) == kIirTileRun, "tile[4] carries a state across one lane's run");
     __shared__ double buf[2 * P * kBlock];
     __shared__ double last[P];
     const int tid = threadIdx.x;
     const unsigned chan = blockIdx.x;
     double* mine = states + (unsigned long long)chan * s.tiles_per_chan * P;
+    const IirMatrix& step = tables->tile[0];
     double carry[P];
 #pragma unroll
     for (int k = 0; k < P; ++k)  // state_in is oldest first
         carry[k] = state_in ? state_in[(unsigned long long)chan * s.state_stride + (P - 1 - k)] : 0.0;
-    for (unsigned base = 0; base < s.tiles_per_chan; base += kBlock) {
-        const unsigned t = base + tid;
-        double st[P];
+    for (unsigned base = 0; base < s.tiles_per_chan; base += kBlock * kIirTileRun) {
+        const unsigned t0 = base + tid * kIirTileRun;
+        // tiles past the end count as tiles that reach the zero state from zero: nothing after them is used
+        double st[P], z[P];
 #pragma unroll
-        for (int k = 0; k < P; ++k) st[k] = t < s.tiles_per_chan ? mine[(unsigned long long)t * P + k] : 0.0;
-        if (tid == 0) add_matvec<P>(st, tables->tile[0], carry);  // what the first tile of this pass ends in
-        scan_states<P>(st, tables->tile, buf, tid);
-        // the state a tile starts from is what the tile before it ends in
-        double* b = buf;  // free: the scan's last level wrote the other half, and a barrier follows below
+        for (int k = 0; k < P; ++k) st[k] = 0.0;
+        for (int j = 0; j < kIirTileRun; ++j) {
+            const unsigned t = t0 + j;
+#pragma unroll
+            for (int k = 0; k < P; ++k) z[k] = t < s.tiles_per_chan ? mine[(unsigned long long)t * P + k] : 0.0;
+            add_matvec<P>(z, step, st);  // z + A^4096 * st
+#pragma unroll
+            for (int k = 0; k < P; ++k) st[k] = z[k];
+        }
+        if (tid == 0) add_matvec<P>(st, tables->tile[4], carry);  // what the first lane of this pass ends in
+        scan_states<P>(st, tables->tile + 4, buf, tid);
+        // a lane starts from what the lane before it ends in
         __syncthreads();
 #pragma unroll
-        for (int k = 0; k < P; ++k) b[k * kBlock + tid] = st[k];
+        for (int k = 0; k < P; ++k) buf[k * kBlock + tid] = st[k];
         if (tid == kBlock - 1) {
 #pragma unroll
             for (int k = 0; k < P; ++k) last[k] = st[k];
         }
         __syncthreads();
-        if (t < s.tiles_per_chan) {
 #pragma unroll
-            for (int k = 0; k < P; ++k) mine[(unsigned long long)t * P + k] = tid == 0 ? carry[k] : b[k * kBlock + tid - 1];
+        for (int k = 0; k < P; ++k) st[k] = tid == 0 ? carry[k] : buf[k * kBlock + tid - 1];
+        for (int j = 0; j < kIirTileRun; ++j) {
+            const unsigned t = t0 + j;
+            if (t >= s.tiles_per_chan) break;
+#pragma unroll
+            for (int k = 0; k < P; ++k) {
+                z[k] = mine[(unsigned long long)t * P + k];
+                mine[(unsigned long long)t * P + k] = st[k];  // the state tile t starts from
+            }
+            add_matvec<P>(z, step, st);
+#pragma unroll
+            for (int k = 0; k < P; ++k) st[k] = z[k];
         }
 #pragma unroll
         for (int k = 0; k < P; ++k) carry[k] = last[k];
@@ -494,7 +516,7 @@ bool iir_tables_usable(const double* a, int order) {
     double m[kIirMaxOrder][kIirMaxOrder] = {}, t[kIirMaxOrder][kIirMaxOrder];
     for (int r = 0; r < order; ++r)
         for (int c = 0; c < order; ++c) m[r][c] = r == 0 ? -a[c] : (c == r - 1 ? 1.0 : 0.0);
-    for (int step = 0; step < 4 + 2 * kIirLevels - 1; ++step) {
+    for (int step = 0; step < 4 + kIirLevels + kIirTileLevels - 1; ++step) {
         for (int r = 0; r < order; ++r)
             for (int c = 0; c < order; ++c) {
                 double acc = 0.0;
