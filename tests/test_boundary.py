@@ -57,6 +57,15 @@ def test_no_silent_cpu_path(dsp):
     assert e.value.code == -2
 
 
+def test_c_abi_header_is_plain_c():
+    """include/dspx.h is the boundary a C, cgo or JNI caller binds: it must compile as C11 and as C++17 on its own."""
+    hdr = os.path.join(ROOT, "include", "dspx.h")
+    for cmd in (["gcc", "-std=c11", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c", hdr],
+                ["g++", "-std=c++17", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c++", hdr]):
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=60)
+        assert r.returncode == 0, r.stderr
+
+
 def test_pipe_thresholds_mirror_the_library(dsp):
     """The constants the benchmark labels its kernels by are the ones the library selects pipes with."""
     src = open(os.path.join(ROOT, "dsp_amd", "csrc", "dspx_common.h")).read()
