@@ -41,6 +41,8 @@ SIGNATURES = {
                                       C.c_size_t, C.c_size_t, C.c_uint]),
     "dspx_lfilter_f64": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t,
                                    C.c_size_t, C.c_size_t, C.c_uint]),
+    "dspx_lfilter_f64_stream": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_uint]),
     "dspx_lfilter_f64_multi": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
                                          C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, C.c_uint]),
     "dspx_lfilter_workspace_bytes": (C.c_size_t, [C.c_size_t, C.c_size_t, C.c_size_t]),

@@ -88,6 +88,19 @@ def lfilter_iir(b, a, x, exact: bool = False, mfma=None, ngpus=None) -> np.ndarr
     return y.reshape(x.shape)
 
 
+def lfilter_iir_stream(b, a, xhist, yhist, x, exact: bool = False) -> np.ndarray:
+    """One chunk of a recursive filter's stream: `xhist` (nb-1 per channel) and `yhist` (na-1 per channel), oldest
+    first, carry the state and are updated in place (dspx_lfilter_f64_stream)."""
+    b, a, x = _np_f64(b), _np_f64(np.atleast_1d(a)), _np_f64(x)
+    x2 = x.reshape(1, -1) if x.ndim == 1 else x
+    for h, w in ((xhist, max(b.size - 1, 0)), (yhist, max(a.size - 1, 0))):
+        assert isinstance(h, np.ndarray) and h.dtype == np.float64 and h.flags.c_contiguous and h.size == x2.shape[0] * w
+    y = np.empty_like(x2)
+    check(lib().dspx_lfilter_f64_stream(b.ctypes.data, b.size, a.ctypes.data, a.size, xhist.ctypes.data, yhist.ctypes.data,
+                                        x2.ctypes.data, y.ctypes.data, x2.shape[0], x2.shape[1], x2.shape[1], _flags(exact)))
+    return y.reshape(x.shape)
+
+
 def lfilter_iir_device(b, a, x, out=None, xhist=None, yhist=None, exact: bool = False, mfma=None):
     """dspx_lfilter_f64_dev on torch CUDA tensors: `b` (device taps), `a` (host coefficients), x/out
     [nchan, n] or [n]; xhist / yhist: the samples / outputs that precede the call, oldest first."""

@@ -89,6 +89,7 @@ struct Tail {
     dspx::IirCoef coef{};
     int order = 0;
     bool exact = false, scan = false;
+    const double* y0 = nullptr;  // host-pointer paths: per channel the `order` outputs before y[0], oldest first
 };
 
 // Fills `t` from the denominators; a[0] is never read (dsp.hpp:366 starts at j = 1).
@@ -393,10 +394,16 @@ struct Pipeline {
             DSPX_HIP(hipEventRecord(s.done, s.stream));
             return DSPX_OK;
         }
-        if (int grc = grow_slot(s, g.taps_pad + g.in_pitch * p.cnt, g.out_pitch * p.cnt,
+        // the outputs that precede a channel's first piece, when the caller supplied them, travel behind the rows
+        const bool with_y0 = tail->order && tail->y0 && p.s0 == 0;
+        const size_t y0_off = g.taps_pad + g.in_pitch * p.cnt;
+        if (int grc = grow_slot(s, y0_off + (with_y0 ? p.cnt * (size_t)tail->order : 0), g.out_pitch * p.cnt,
                                 tail_workspace_bytes(*tail, p.cnt, p.len)))
             return grc;
         if (ntaps) std::memcpy(s.pin_in, taps, ntaps * sizeof(double));
+        if (with_y0)
+            std::memcpy(s.pin_in + y0_off, tail->y0 + p.c * (size_t)tail->order,
+                        p.cnt * (size_t)tail->order * sizeof(double));
         // history: the lead samples that exist in the caller's buffer; before them the caller's
         // initial history (samples s0 .. hl-1 of it when lead == s0 < hl), or zeros
         const size_t lead = std::min(g.hl, p.s0);
@@ -416,7 +423,7 @@ struct Pipeline {
             }
             std::memcpy(row + g.hl_pad, xr + p.s0, p.len * sizeof(double));
         }
-        DSPX_HIP(hipMemcpyAsync(s.d_in, s.pin_in, (g.taps_pad + g.in_pitch * p.cnt) * sizeof(double),
+        DSPX_HIP(hipMemcpyAsync(s.d_in, s.pin_in, (y0_off + (with_y0 ? p.cnt * (size_t)tail->order : 0)) * sizeof(double),
                                 hipMemcpyHostToDevice, s.stream));
         const double* d_rows = s.d_in + g.taps_pad;
         const bool fused = tail_fuses_fir(*tail, ntaps, flags);
@@ -428,7 +435,7 @@ struct Pipeline {
         if (tail->order) {
             // a piece that continues a channel starts from the last outputs of the piece before it, which
             // runs on another stream: wait for it (pieces of a channel are issued in order by one thread)
-            const double* d_state = nullptr;
+            const double* d_state = with_y0 ? s.d_in + y0_off : nullptr;
             if (p.s0 > 0) {
                 DSPX_HIP(hipStreamWaitEvent(s.stream, eng->slots[(i - 1) % kSlots].done, 0));
                 d_state = eng->d_tail_state;
@@ -703,6 +710,34 @@ int dspx_lfilter_f64_multi(const double* b, size_t nb, const double* a, size_t n
     Tail tail;
     if (int rc = make_tail(a, na, flags, tail)) return rc;
     return host_path(b, nb, nullptr, x, y, nchan, n, stride, ngpus, flags, tail);
+}
+
+int dspx_lfilter_f64_stream(const double* b, size_t nb, const double* a, size_t na, double* xhist, double* yhist,
+                            const double* x, double* y, size_t nchan, size_t n, size_t stride, unsigned flags) {
+    if (int rc = dspx::check_flags(flags)) return rc;
+    Tail tail;
+    if (int rc = make_tail(a, na, flags, tail)) return rc;
+    const size_t hl = nb ? nb - 1 : 0, P = (size_t)tail.order;
+    if ((hl && nchan && !xhist) || (P && nchan && !yhist)) return fail(DSPX_ERR_INVALID, "history is NULL");
+    if (!(flags & DSPX_FIR_MFMA)) flags |= DSPX_FIR_VECTOR;  // as dspx_fir_f64_stream
+    tail.y0 = P ? yhist : nullptr;
+    if (int rc = host_path(b, nb, hl ? xhist : nullptr, x, y, nchan, n, stride, -1, flags, tail)) return rc;
+    // the next chunk's histories: the last nb-1 samples of [xhist | x], the last na-1 outputs of [yhist | y]
+    auto roll = [&](double* hist, size_t w, const double* data) {
+        for (size_t c = 0; c < nchan && w && n; ++c) {
+            double* h = hist + c * w;
+            const double* d = data + c * stride;
+            if (n >= w) {
+                std::copy(d + (n - w), d + n, h);
+            } else {
+                std::copy(h + n, h + w, h);
+                std::copy(d, d + n, h + (w - n));
+            }
+        }
+    };
+    roll(xhist, hl, x);
+    roll(yhist, P, y);
+    return DSPX_OK;
 }
 
 size_t dspx_lfilter_workspace_bytes(size_t na, size_t nchan, size_t n) {

@@ -270,7 +270,8 @@ std::vector<T> lfilter(const Container_1& numerators, T denominator, const Conta
 // the concatenated results do not depend on where the stream is cut (bit for bit); they agree
 // with one lfilter call over the whole stream to rounding (that call may use the matrix pipe).
 template <typename T = double> struct lfilter_stream_t {
-    std::vector<T> history;  // ntaps-1 samples; (re)initialised to zeros when its size does not fit
+    std::vector<T> history;         // ntaps-1 samples; (re)initialised to zeros when its size does not fit
+    std::vector<T> output_history;  // denominators.size()-1 outputs (recursive filters only), likewise
     std::vector<T> result;
 };
 
@@ -289,6 +290,36 @@ void lfilter(lfilter_stream_t<T>& stream, const Container_1& numerators, const C
     const detail::double_view<Container_2> in(x);
     const int rc = dspx_fir_f64_stream(b.data(), b.size(), stream.history.data(), in.data(), stream.result.data(), 1,
                                        n, n, DSPX_FIR_FMA);
+    if (rc != DSPX_OK)
+        throw std::runtime_error(std::string("dsp::lfilter (MI355X): ") + dspx_status_string(rc) + ": " +
+                                 dspx_last_error());
+}
+
+// The same with a recursive part (reference dsp.hpp:366-368): the stream also carries the last
+// denominators.size()-1 outputs.  Chunked results agree with one call over the whole stream to rounding.
+template <typename T = double, typename Container_1, typename Container_2, typename Container_3>
+    requires std::floating_point<T> && indexable_of<Container_1, T> && indexable_of<Container_2, T> &&
+             indexable_of<Container_3, T>
+void lfilter(lfilter_stream_t<T>& stream, const Container_1& numerators, const Container_2& denominators,
+             const Container_3& x) {
+    static_assert(std::is_same_v<T, double> && std::is_same_v<typename Container_1::value_type, double> &&
+                    std::is_same_v<typename Container_2::value_type, double> &&
+                    std::is_same_v<typename Container_3::value_type, double>,
+                  "dsp::lfilter (MI355X): only T = double over containers of double is implemented");
+    const std::size_t n = x.size();
+    const std::size_t keep = numerators.size() ? numerators.size() - 1 : 0;
+    const std::size_t keep_out = denominators.size() ? denominators.size() - 1 : 0;
+    if (stream.history.size() != keep) stream.history.assign(keep, 0.0);
+    if (stream.output_history.size() != keep_out) stream.output_history.assign(keep_out, 0.0);
+    if (stream.result.size() != n) stream.result.resize(n);
+    if (n == 0) return;
+    const detail::double_view<Container_1> b(numerators);
+    const detail::double_view<Container_2> a(denominators);
+    const detail::double_view<Container_3> in(x);
+    const int rc = dspx_lfilter_f64_stream(b.data(), b.size(), a.data(), a.size(), stream.history.data(),
+                                           stream.output_history.data(), in.data(), stream.result.data(), 1, n, n,
+                                           DSPX_FIR_FMA);
+    if (rc == DSPX_ERR_INVALID) throw std::invalid_argument(std::string("dsp::lfilter (MI355X): ") + dspx_last_error());
     if (rc != DSPX_OK)
         throw std::runtime_error(std::string("dsp::lfilter (MI355X): ") + dspx_status_string(rc) + ": " +
                                  dspx_last_error());

@@ -113,6 +113,15 @@ DSPX_API int dspx_fir_f64_stream(const double* taps, size_t ntaps, double* hist,
 DSPX_API int dspx_lfilter_f64(const double* b, size_t nb, const double* a, size_t na, const double* x, double* y,
                               size_t nchan, size_t n, size_t stride, unsigned flags);
 
+/* Streaming form of dspx_lfilter_f64 (no counterpart in the reference): xhist (nchan x (nb-1)) and yhist
+ * (nchan x (na-1)), oldest first, hold the samples and outputs that precede this chunk and are updated for
+ * the next one.  The FIR part runs on the vector pipe unless DSPX_FIR_MFMA is given (as dspx_fir_f64_stream).
+ * With DSPX_FIR_EXACT chunked calls reproduce one long call bit for bit; in the default mode they agree to
+ * rounding (the block-parallel tail rounds by position inside a call). */
+DSPX_API int dspx_lfilter_f64_stream(const double* b, size_t nb, const double* a, size_t na, double* xhist,
+                                     double* yhist, const double* x, double* y, size_t nchan, size_t n,
+                                     size_t stride, unsigned flags);
+
 /* Same contract, sharded over the first `ngpus` devices (0 = all) by contiguous channel ranges.  With a
  * recursive part (na > 1) a channel is never split across devices (its state is a serial dependence), so at
  * most nchan devices work; without one this is dspx_fir_f64_multi. */

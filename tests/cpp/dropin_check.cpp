@@ -203,6 +203,19 @@ int main(int argc, char** argv) {
             lfilter_ctx_t<double> rctx;
             lfilter(rctx, num, den, x);
             CHECK(rctx.result == got);
+            // streamed in chunks with both histories carried
+            lfilter_stream_t<double> rst;
+            std::vector<double> joined;
+            const std::vector<size_t> rcuts = {0, 2, 5, 1000, 1001, 4200, x.size()};
+            for (size_t c = 0; c + 1 < rcuts.size(); ++c) {
+                std::vector<double> chunk(x.begin() + rcuts[c], x.begin() + rcuts[c + 1]);
+                lfilter(rst, num, den, chunk);
+                joined.insert(joined.end(), rst.result.begin(), rst.result.end());
+            }
+            CHECK(joined.size() == want.size() && rst.output_history.size() == 3);
+            worst = 0.0;
+            for (size_t i = 0; i < x.size(); ++i) worst = std::max(worst, std::abs(want[i] - joined[i]));
+            CHECK(worst <= 1e-12 * peak);
             // more than nine denominator coefficients: loud error, no silent CPU path
             CHECK(throws<std::invalid_argument>([&] { lfilter<double>(num, std::vector<double>(10, 0.01), x); }));
         }
