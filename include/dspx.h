@@ -1,5 +1,6 @@
 /*
- * dspx — C ABI of the MI355X (gfx950) FIR engine behind dsp::lfilter(b, 1.0, x).
+ * dspx — C ABI of the MI355X (gfx950) FIR engine behind dsp::lfilter(b, 1.0, x), with the recursive tail
+ * of dsp::lfilter(b, a, x) and the per-scale convolution bank of dsp::cwt on the same kernels.
  *
  * The reference library (Unbinilium/DSP, dsp/include/dsp.hpp) is a header-only C++
  * template library with no FFI of its own; the interface this ABI replaces is the
