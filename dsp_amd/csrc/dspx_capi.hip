@@ -502,11 +502,11 @@ int run_pipeline(Pipeline& pl, size_t max_threads) {
         }
         // copy threads per direction: measured on an MI355X host, 1 / 2 / 3 threads move 3.2 / 3.7 / 4.1 G
         // samples/s end to end; more than 3 gain little and take cores from the caller
-        size_t nthreads = std::min<size_t>(max_threads, pieces.size() >= 32 ? 3 : pieces.size() >= 8 ? 2 : 1);
-        if (pl.tail->order)  // pieces that continue a channel must be issued in order
+        const size_t nthreads = std::min<size_t>(max_threads, pieces.size() >= 32 ? 3 : pieces.size() >= 8 ? 2 : 1);
+        size_t producers = pl.d_src ? 1 : nthreads;  // issuing a download costs the host nothing
+        if (pl.tail->order)  // pieces that continue a channel must be issued in order, by one thread
             for (const Piece& p : pieces)
-                if (p.s0 > 0) nthreads = 1;
-        const size_t producers = pl.d_src ? 1 : nthreads;  // issuing a download costs the host nothing
+                if (p.s0 > 0) producers = 1;
         std::vector<std::thread> workers;
         for (size_t k = 0; k < nthreads; ++k) workers.emplace_back([&pl, k, nthreads] { pl.consumer(k, nthreads); });
         for (size_t k = 1; k < producers; ++k) workers.emplace_back([&pl, k, producers] { pl.producer(k, producers); });
