@@ -430,7 +430,7 @@ __global__ __launch_bounds__(kSeqChans) void iir_seq_kernel(IirCoef coef, double
     const int rows = (int)min((unsigned long long)kSeqChans, s.nchan - c0);
     const bool have = lane < rows;
     double st[P];
-    long long known = 0;  // how many outputs before the current sample exist (the reference skips the others)
+    int known = 0;  // how many outputs before the current sample exist, up to P (the reference skips the others)
 #pragma unroll
     for (int k = 0; k < P; ++k) st[k] = 0.0;
     if (state_in && have) {
@@ -444,7 +444,9 @@ __global__ __launch_bounds__(kSeqChans) void iir_seq_kernel(IirCoef coef, double
             if (lane < cols) blk[r][lane] = y[(c0 + r) * s.y_stride + i0 + lane];
         __syncthreads();
         if (have) {
-            for (int t = 0; t < cols; ++t) {
+            int t = 0;
+            // until P outputs exist the reference subtracts only the terms it has (dsp.hpp:359)
+            for (; t < cols && known < P; ++t) {
                 double acc = blk[lane][t];
 #pragma unroll
                 for (int j = 0; j < P; ++j)
@@ -452,7 +454,34 @@ __global__ __launch_bounds__(kSeqChans) void iir_seq_kernel(IirCoef coef, double
 #pragma unroll
                 for (int k = P - 1; k > 0; --k) st[k] = st[k - 1];
                 st[0] = acc;
-                known = min(known + 1, (long long)P);
+                ++known;
+                blk[lane][t] = acc;
+            }
+            // steady state, eight samples at a time: their LDS reads are issued together, off the dependent chain
+            for (; t + 8 <= cols; t += 8) {
+                double v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = blk[lane][t + u];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    double acc = v[u];
+#pragma unroll
+                    for (int j = 0; j < P; ++j) acc = tail_step<EXACT>(coef.a[j], st[j], acc);
+#pragma unroll
+                    for (int k = P - 1; k > 0; --k) st[k] = st[k - 1];
+                    st[0] = acc;
+                    v[u] = acc;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) blk[lane][t + u] = v[u];
+            }
+            for (; t < cols; ++t) {
+                double acc = blk[lane][t];
+#pragma unroll
+                for (int j = 0; j < P; ++j) acc = tail_step<EXACT>(coef.a[j], st[j], acc);
+#pragma unroll
+                for (int k = P - 1; k > 0; --k) st[k] = st[k - 1];
+                st[0] = acc;
                 blk[lane][t] = acc;
             }
         }
