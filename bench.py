@@ -34,6 +34,8 @@ WORKLOADS = {
                    "batched multichannel 4096 x 2^20 samples, 255-tap firwin(255, 0.25) (BASELINE configs[2])"),
     "long101": (1, 1 << 28, 101, 0.25, "single stream 2^28 samples, 101-tap firwin(101, 0.25) (BASELINE configs[1])"),
     "long4095": (1, 1 << 26, 4095, 0.1, "single stream 2^26 samples, 4095-tap firwin(4095, 0.1) (BASELINE configs[3])"),
+    "batched31": (4096, 1 << 20, 31, 0.25,
+                  "batched multichannel 4096 x 2^20 samples, 31-tap firwin(31, 0.25) (the HBM-bound regime of the metric)"),
     "small255": (64, 1 << 20, 255, 0.25, "reduced batch 64 x 2^20 samples, 255 taps (development only)"),
 }
 # dsp::cwt bank (BASELINE configs[4]): Morlet table of 2^10 points, integer scales 1..65, 2^22 samples.
