@@ -328,6 +328,8 @@ def main() -> None:
     backend = os.environ.get("DSPX_BENCH_BACKEND", "nccl")
     if os.environ.get("DSPX_BENCH_ONE_DEVICE") == "1":
         local_rank = 0
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} GPU(s) visible")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     red_dev = dev if backend == "nccl" else torch.device("cpu")   # where the timing reductions live
