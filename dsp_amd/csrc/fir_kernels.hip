@@ -445,8 +445,41 @@ __global__ __launch_bounds__(kBlock) void fir_f64_mfma_kernel(const double* __re
         bad = bad_flag != 0;  // workgroup-uniform
         if (bad) break;
 
-        // two steps per iteration: ten LDS reads are issued together, then eight products
-        for (int e = 0; e + 1 < steps; e += 2) {
+        // A sample vector read for row block 0 at step e is the operand of row block 1 at step e + 4, of block 2
+        // at e + 8, ...: iterations of 4*(OB-1) steps keep those in registers, so a step reads one new sample
+        // vector and one tap vector from LDS instead of OB + 1 (less LDS traffic: the chip is power-bound here,
+        // and the saving shows up as clock).
+        // Worth it with four row blocks (+1..3 %); with two it saves one read in three and costs ten registers
+        // (-0.5 %), so that tiling reads every operand from LDS in the loop further down.
+        constexpr int kRing = 4 * (OB - 1);
+        constexpr bool kUseRing = OB == 4;
+        auto sample_vec = [&](int off) { return imgd[b_base + off + 2 * (off >> G::kShift)]; };
+        double ring[kRing];  // ring[j] = the block-0 operand of step e - kRing + j
+        if constexpr (kUseRing) {
+#pragma unroll
+            for (int j = 0; j < kRing; ++j) ring[j] = sample_vec(12 + 4 * (kRing - j));
+        }
+        int e_first = 0;
+        for (; kUseRing && e_first + kRing <= steps; e_first += kRing) {
+            double f[kRing], a[kRing];
+#pragma unroll
+            for (int u = 0; u < kRing; ++u) {
+                f[u] = sample_vec(12 - 4 * (e_first + u));
+                a[u] = tapz[a_base + 4 * (e_first + u)];
+            }
+#pragma unroll
+            for (int u = 0; u < kRing; ++u) {
+#pragma unroll
+                for (int ob = 0; ob < OB; ++ob) {
+                    const double bv = u >= 4 * ob ? f[u - 4 * ob] : ring[kRing - 4 * ob + u];
+                    acc[ob] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], bv, acc[ob], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < kRing; ++j) ring[j] = f[j];
+        }
+        // the remaining steps (all of them without the ring), two per iteration with every operand read from LDS
+        for (int e = e_first; e + 1 < steps; e += 2) {
             const double a0 = tapz[a_base + 4 * e];
             const double a1 = tapz[a_base + 4 * e + 4];
             double b0[OB], b1[OB];
@@ -464,7 +497,7 @@ __global__ __launch_bounds__(kBlock) void fir_f64_mfma_kernel(const double* __re
             for (int ob = 0; ob < OB; ++ob)
                 acc[ob] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1[ob], acc[ob], 0, 0, 0);
         }
-        if (steps & 1) {  // the band's last step
+        if ((steps - e_first) & 1) {  // the band's last step
             const int e = steps - 1;
             const double a0 = tapz[a_base + 4 * e];
             double b0[OB];

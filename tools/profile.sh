@@ -4,7 +4,7 @@
 #   tools/profile.sh <tag> [bench args...]
 set -u
 TAG=${1:-run}; shift || true
-ARGS="--steps 5 --warmup 1 --no-cpu-baseline $*"
+ARGS="--steps 20 --warmup 3 --no-cpu-baseline $*"   # the benchmark's own step counts
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp 2>/dev/null && export TMPDIR=/tmp && cd - >/dev/null
