@@ -292,7 +292,7 @@ __global__ __launch_bounds__(kBlock) void fir_f64_kernel(const double* __restric
 // adds, to output i0 + m of every segment, the four taps d+m-3 .. d+m.  A is the same 16x4
 // Toeplitz block for every segment and every i0 (one LDS read per step from a zero-padded copy
 // of the stage's taps); B is four consecutive input samples of each segment (one LDS read per
-// product).  A filter of N taps takes floor((N+2)/4) + 4 steps: the band is N + 15 columns
+// product, or per step where the operand ring of the four-block tiling reuses it across row blocks).  A filter of N taps takes floor((N+2)/4) + 4 steps: the band is N + 15 columns
 // wide instead of N, so 6 % of the multiplies are by zero at 255 taps and 0.4 % at 4095.
 //
 // Why it exists: on random data the chip holds ~2.39 GHz while issuing these products but only
