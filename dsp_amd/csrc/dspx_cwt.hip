@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <numeric>
 #include <stdexcept>
 #include <string>
@@ -201,24 +202,41 @@ int apply_bank(const dspx_cwt_bank* bank, const double* d_signal, size_t n, doub
     return DSPX_OK;
 }
 
-// Host-pointer transform on one device: the rows `pick` of the sorted scales.
+// Host-pointer transform on one device: the rows `pick` of the sorted scales.  The result of a pass (rows x n
+// doubles) lives in device memory until it is downloaded; when all rows do not fit in half of the free device
+// memory the rows are transformed in several passes (DSPX_CWT_ROWS_PER_PASS caps the rows of a pass further).
 int run_cwt_device(int device, const Tables& t, const double* psi, const std::vector<size_t>& pick,
                    const double* signal, size_t n, double* result, unsigned flags) {
     if (pick.empty()) return DSPX_OK;
     DSPX_HIP(hipSetDevice(device));
+    const size_t pitch = (n + 1) & ~size_t(1);
+    size_t free_b = 0, total_b = 0;
+    DSPX_HIP(hipMemGetInfo(&free_b, &total_b));
+    const size_t sig_bytes = n * sizeof(double);
+    const size_t budget = free_b / 2 > sig_bytes ? free_b / 2 - sig_bytes : 0;
+    size_t per_pass = std::max<size_t>(1, std::min(pick.size(), budget / (pitch * sizeof(double))));
+    if (const char* e = std::getenv("DSPX_CWT_ROWS_PER_PASS")) {
+        const long cap = std::atol(e);
+        if (cap > 0) per_pass = std::min(per_pass, (size_t)cap);
+    }
     dspx_cwt_bank* bank = nullptr;
     double *d_sig = nullptr, *d_res = nullptr;
-    const size_t pitch = (n + 1) & ~size_t(1);
     auto body = [&]() -> int {
-        std::vector<size_t> local(pick.size());
-        std::iota(local.begin(), local.end(), size_t(0));
-        if (int rc = make_bank(t, psi, pick, local, &bank)) return rc;
-        DSPX_HIP(hipMalloc(&d_sig, n * sizeof(double)));
-        DSPX_HIP(hipMalloc(&d_res, pitch * pick.size() * sizeof(double)));
-        DSPX_HIP(hipMemcpy(d_sig, signal, n * sizeof(double), hipMemcpyHostToDevice));
-        if (int rc = apply_bank(bank, d_sig, n, d_res, pitch, flags, nullptr)) return rc;
-        DSPX_HIP(hipDeviceSynchronize());
-        return dspx::download_rows(device, d_res, pitch, pick.size(), n, result, n, pick.data());
+        DSPX_HIP(hipMalloc(&d_sig, sig_bytes));
+        DSPX_HIP(hipMalloc(&d_res, pitch * per_pass * sizeof(double)));
+        DSPX_HIP(hipMemcpy(d_sig, signal, sig_bytes, hipMemcpyHostToDevice));
+        for (size_t r0 = 0; r0 < pick.size(); r0 += per_pass) {
+            const std::vector<size_t> rows(pick.begin() + (long)r0, pick.begin() + (long)std::min(pick.size(), r0 + per_pass));
+            std::vector<size_t> local(rows.size());
+            std::iota(local.begin(), local.end(), size_t(0));
+            if (int rc = make_bank(t, psi, rows, local, &bank)) return rc;
+            if (int rc = apply_bank(bank, d_sig, n, d_res, pitch, flags, nullptr)) return rc;
+            DSPX_HIP(hipDeviceSynchronize());
+            if (int rc = dspx::download_rows(device, d_res, pitch, rows.size(), n, result, n, rows.data())) return rc;
+            dspx_cwt_bank_destroy(bank);
+            bank = nullptr;
+        }
+        return DSPX_OK;
     };
     const int rc = body();
     const std::string keep = dspx::g_last_error;

@@ -179,7 +179,10 @@ DSPX_API int dspx_integrate_wavelet_morlet_f64(size_t precision, double lower, d
  * Errors: where the reference throws std::invalid_argument -> DSPX_ERR_INVALID; where it throws
  * std::runtime_error ("Selected scale is too large/small", no scales) -> DSPX_ERR_DOMAIN; the
  * reference's message is in dspx_last_error().  A table of a single tap, on which the reference
- * fails an assertion (dsp.hpp:1193), is reported as "too small". */
+ * fails an assertion (dsp.hpp:1193), is reported as "too small". 
+ * The result of a pass stays in device memory until it is downloaded; when all rows do not fit in half of the
+ * free device memory they are transformed in several passes (the environment variable DSPX_CWT_ROWS_PER_PASS
+ * caps the rows of a pass further).  Rows do not depend on how they are grouped. */
 DSPX_API int dspx_cwt_f64(const double* signal, size_t n, const double* scales, size_t nscales, const double* psi,
                           size_t npsi, const double* wx, size_t nx, double* result, unsigned flags);
 /* The same, with the scales sharded over the first `ngpus` devices (0 = all), balanced by the sum of

@@ -178,3 +178,19 @@ def test_device_bank_65_scales(dsp, oracle, golden):
     sig2[1:] = sig
     assert torch.equal(bank.apply(sig2[1:]), out)
     bank.close()
+
+
+@pytest.mark.gpu
+def test_cwt_host_path_in_several_passes(dsp, oracle, golden, monkeypatch):
+    """When the rows of a transform do not fit in device memory together they are transformed in passes;
+    DSPX_CWT_ROWS_PER_PASS forces that on a small case (here 7 scales, 3 rows per pass): same bits as one pass."""
+    psi, wx = golden["morlet10_psi"], golden["morlet10_x"]
+    sig = oracle.fill_splitmix(6000, dsp.SEED, 3)
+    scales = [1.0, 2.5, 7.0, 12.0, 20.0, 33.0, 64.0]
+    one = dsp.cwt(sig, scales, psi, wx)
+    monkeypatch.setenv("DSPX_CWT_ROWS_PER_PASS", "3")
+    several = dsp.cwt(sig, scales, psi, wx)
+    assert np.array_equal(one.view(np.uint64), several.view(np.uint64))
+    ref = oracle.cwt(sig, scales, psi, wx)
+    for a, b in zip(several, ref):
+        assert scaled_err(a, b) <= TOL
