@@ -500,9 +500,10 @@ int run_pipeline(Pipeline& pl, size_t max_threads) {
                 if (int crc = pl.consume(i)) return crc;
             return DSPX_OK;
         }
-        // copy threads per direction: measured on an MI355X host, 1 / 2 / 3 threads move 3.2 / 3.7 / 4.1 G
-        // samples/s end to end; more than 3 gain little and take cores from the caller
-        const size_t nthreads = std::min<size_t>(max_threads, pieces.size() >= 32 ? 3 : pieces.size() >= 8 ? 2 : 1);
+        // copy threads per direction: measured on an MI355X host, 1 / 2 / 3 / 4 threads move 3.2 / 3.7 / 4.1 / 4.3 G
+        // samples/s end to end; more gain nothing and take cores from the caller
+        const size_t nthreads =
+            std::min<size_t>(max_threads, pieces.size() >= 64 ? 4 : pieces.size() >= 32 ? 3 : pieces.size() >= 8 ? 2 : 1);
         size_t producers = pl.d_src ? 1 : nthreads;  // issuing a download costs the host nothing
         if (pl.tail->order)  // pieces that continue a channel must be issued in order, by one thread
             for (const Piece& p : pieces)
@@ -554,7 +555,7 @@ int host_path(const double* taps, size_t ntaps, const double* hist0, const doubl
     if (ngpus < 0) {  // single-device entry points: stay on the caller's current device
         std::vector<Piece> pieces;
         cut_pieces(0, nchan, 0, n, pieces);
-        return run_device(cur, taps, ntaps, hist0, x, y, stride, pieces, flags, 3, tail);
+        return run_device(cur, taps, ntaps, hist0, x, y, stride, pieces, flags, 4, tail);
     }
     int G = ngpus == 0 ? ndev : ngpus;
     if (G > ndev) return fail(DSPX_ERR_INVALID, "ngpus (%d) exceeds visible devices (%d)", G, ndev);
@@ -591,7 +592,7 @@ int download_rows(int device, const double* d_src, size_t src_pitch, size_t rows
     const Tail none;
     Pipeline pl(device, eng, nullptr, nullptr, nullptr, dst, 0, dst_stride, 0, &pieces, &none);
     pl.d_src = d_src, pl.d_src_pitch = src_pitch, pl.row_map = row_map;
-    return run_pipeline(pl, 3);
+    return run_pipeline(pl, 4);
 }
 
 }  // namespace dspx
