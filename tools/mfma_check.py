@@ -1,3 +1,5 @@
+"""Quick check of the matrix-pipe FIR kernel against the oracle over tap counts and lengths around its
+tile and stage boundaries (development aid; the test-suite covers the same ground).  Run from the repository root."""
 import sys, os
 sys.path.insert(0, os.getcwd())
 import numpy as np, dsp_amd
