@@ -89,6 +89,7 @@ struct Tail {
     dspx::IirCoef coef{};
     int order = 0;
     bool exact = false, scan = false;
+    unsigned lane_plain = 0, tile_plain = 0;  // dspx::IirPlan
     const double* y0 = nullptr;  // host-pointer paths: per channel the `order` outputs before y[0], oldest first
 };
 
@@ -105,7 +106,9 @@ int make_tail(const double* a, size_t na, unsigned flags, Tail& t) {
     t.exact = (flags & DSPX_FIR_EXACT) != 0;
     // a recurrence whose state grows without bound (or non-finite coefficients) leaves the block-parallel
     // path without usable matrix powers: such filters run on the sequential kernel
-    t.scan = !t.exact && dspx::iir_tables_usable(t.coef.a, t.order);
+    const dspx::IirPlan plan = dspx::iir_plan(t.coef.a, t.order);
+    t.scan = !t.exact && plan.usable;
+    t.lane_plain = plan.lane_plain, t.tile_plain = plan.tile_plain;
     return DSPX_OK;
 }
 
@@ -136,6 +139,7 @@ int launch_tail(const Tail& t, double* d_y, size_t y_stride, const double* d_sta
         s.tiles_per_chan = (unsigned)tiles;
         s.nchan = (unsigned)std::min(chans_per_launch, nchan - c0);
         s.vec2 = aligned16(d_y) && y_stride % 2 == 0;
+        s.lane_plain = t.lane_plain, s.tile_plain = t.tile_plain;
         const double* st = d_state ? d_state + c0 * state_stride : nullptr;
         if (t.scan) {  // launches on one stream run in order, so the workspace is reused from launch to launch
             dspx::IirFront f{};

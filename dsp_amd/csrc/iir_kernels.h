@@ -53,15 +53,25 @@ struct IirShape {
     unsigned tiles_per_chan;          // ceil(n / kIirTile)
     unsigned nchan;
     int vec2;                         // y is 16-byte aligned and y_stride is even: 16-byte global accesses
+    unsigned lane_plain, tile_plain;  // bit d: level d of that scan may use plain products (IirPlan)
 };
 
 // Bytes of device workspace the scan path needs for `nchan` channels of `n` samples (tables + one
 // state per tile).
 size_t iir_workspace_bytes(size_t nchan, size_t n, int order);
 
-// True when every entry of the matrix powers stays far below overflow, i.e. the scan path can be used;
-// otherwise (a recurrence that grows without bound) only the sequential kernel is meaningful.
-bool iir_tables_usable(const double* a, int order);
+// What the host learns from the matrix powers (computed in double, as the device computes them in
+// double-double).  usable: every entry stays far below overflow, i.e. the scan path can be used; otherwise
+// (a recurrence that grows without bound, non-finite coefficients) only the sequential kernel is meaningful.
+// lane_plain / tile_plain, bit d: the power used at level d of the lane / tile scan has absolute row sums of
+// at most 1 / (16 (P + 1)), so applying it with plain fused multiply-adds perturbs a state by less than
+// eps / 16 of its own size per level -- far below the rounding of the recurrence itself -- and the compensated
+// products are kept for the levels whose powers are not yet small (all of them for poles next to the unit circle).
+struct IirPlan {
+    bool usable;
+    unsigned lane_plain, tile_plain;
+};
+IirPlan iir_plan(const double* a, int order);
 
 // Block-parallel path (fused multiply-adds; rounding differs from the sequential loop).  `work` holds
 // iir_workspace_bytes(); `state_in` (nullable) holds per channel the P outputs that precede y[0], oldest first.

@@ -97,10 +97,22 @@ __device__ __forceinline__ void add_matvec(double (&s)[P], const IirMatrix& M, c
     }
 }
 
+// The same with plain fused multiply-adds, for powers whose entries are small (see IirPlan).
+template <int P>
+__device__ __forceinline__ void add_matvec_plain(double (&s)[P], const IirMatrix& M, const double (&p)[P]) {
+#pragma unroll
+    for (int r = 0; r < P; ++r) {
+        double acc = s[r];
+#pragma unroll
+        for (int c = 0; c < P; ++c) acc = __builtin_fma(M.hi[r][c], p[c], acc);
+        s[r] = acc;
+    }
+}
+
 // Inclusive scan over the 256 lanes of a workgroup: s_k <- sum_{i <= k} M0^(k-i) s_i, with M[d] = M0^(2^d).
 // buf: 2 * P * kBlock doubles of LDS (component-major, so lanes hit consecutive banks).
 template <int P>
-__device__ __forceinline__ void scan_states(double (&s)[P], const IirMatrix* M, double* buf, int tid) {
+__device__ __forceinline__ void scan_states(double (&s)[P], const IirMatrix* M, unsigned plain, double* buf, int tid) {
     int cur = 0;
     for (int d = 0; d < kIirLevels; ++d) {
         double* b = buf + cur * P * kBlock;
@@ -112,7 +124,10 @@ __device__ __forceinline__ void scan_states(double (&s)[P], const IirMatrix* M, 
             double p[P];
 #pragma unroll
             for (int k = 0; k < P; ++k) p[k] = b[k * kBlock + from];
-            add_matvec<P>(s, M[d], p);
+            if ((plain >> d) & 1u)  // uniform
+                add_matvec_plain<P>(s, M[d], p);
+            else
+                add_matvec<P>(s, M[d], p);
         }
         cur ^= 1;  // the next level writes the other half: nobody can still be reading it (one barrier between)
     }
@@ -250,7 +265,7 @@ __global__ __launch_bounds__(kBlock) void iir_tile_state_kernel(IirCoef coef, Ii
     for (int k = 0; k < P; ++k) st[k] = 0.0;
 #pragma unroll
     for (int t = 0; t < kR; ++t) advance<P>(st, coef, w[t]);
-    scan_states<P>(st, tables->lane, buf, tid);
+    scan_states<P>(st, tables->lane, s.lane_plain, buf, tid);
     if (tid == kBlock - 1) {
         double* dst = states + ((unsigned long long)chan * s.tiles_per_chan + tile) * P;
 #pragma unroll
@@ -287,12 +302,15 @@ __global__ __launch_bounds__(kBlock) void iir_tile_scan_kernel(const IirTables* 
             const unsigned t = t0 + j;
 #pragma unroll
             for (int k = 0; k < P; ++k) z[k] = t < s.tiles_per_chan ? mine[(unsigned long long)t * P + k] : 0.0;
-            add_matvec<P>(z, step, st);  // z + A^4096 * st
+            if (s.tile_plain & 1u)  // z + A^4096 * st
+                add_matvec_plain<P>(z, step, st);
+            else
+                add_matvec<P>(z, step, st);
 #pragma unroll
             for (int k = 0; k < P; ++k) st[k] = z[k];
         }
         if (tid == 0) add_matvec<P>(st, tables->tile[4], carry);  // what the first lane of this pass ends in
-        scan_states<P>(st, tables->tile + 4, buf, tid);
+        scan_states<P>(st, tables->tile + 4, s.tile_plain >> 4, buf, tid);
         // a lane starts from what the lane before it ends in
         __syncthreads();
 #pragma unroll
@@ -312,7 +330,10 @@ __global__ __launch_bounds__(kBlock) void iir_tile_scan_kernel(const IirTables* 
                 z[k] = mine[(unsigned long long)t * P + k];
                 mine[(unsigned long long)t * P + k] = st[k];  // the state tile t starts from
             }
-            add_matvec<P>(z, step, st);
+            if (s.tile_plain & 1u)
+                add_matvec_plain<P>(z, step, st);
+            else
+                add_matvec<P>(z, step, st);
 #pragma unroll
             for (int k = 0; k < P; ++k) st[k] = z[k];
         }
@@ -341,7 +362,7 @@ __device__ __forceinline__ void apply_tile(const IirCoef& coef, const IirFront& 
 #pragma unroll
     for (int t = 0; t < kR; ++t) advance<P>(st, coef, w[t]);
     if (tid == 0) add_matvec<P>(st, tables->lane[0], in);
-    scan_states<P>(st, tables->lane, buf, tid);
+    scan_states<P>(st, tables->lane, s.lane_plain, buf, tid);
     // a lane starts from what the lane before it ends in; the last lane ends in the tile's final state
     __syncthreads();
 #pragma unroll
@@ -540,25 +561,34 @@ size_t iir_workspace_bytes(size_t nchan, size_t n, int order) {
     return kTablesBytes + nchan * tiles * (size_t)order * sizeof(double);
 }
 
-bool iir_tables_usable(const double* a, int order) {
-    // the same squarings as iir_tables_kernel; every entry must stay far from overflow
+IirPlan iir_plan(const double* a, int order) {
+    // the same squarings as iir_tables_kernel: after k of them m = A^(2^k); lane[d] is k = 4 + d, tile[d] is k = 12 + d
+    IirPlan plan{true, 0u, 0u};
+    const double small = 1.0 / (16.0 * (order + 1));
     double m[kIirMaxOrder][kIirMaxOrder] = {}, t[kIirMaxOrder][kIirMaxOrder];
     for (int r = 0; r < order; ++r)
         for (int c = 0; c < order; ++c) m[r][c] = r == 0 ? -a[c] : (c == r - 1 ? 1.0 : 0.0);
-    for (int step = 0; step < 4 + kIirLevels + kIirTileLevels - 1; ++step) {
-        for (int r = 0; r < order; ++r)
+    for (int k = 1; k <= 4 + kIirLevels + kIirTileLevels - 1; ++k) {
+        double worst_row = 0.0;
+        for (int r = 0; r < order; ++r) {
+            double row = 0.0;
             for (int c = 0; c < order; ++c) {
                 double acc = 0.0;
-                for (int k = 0; k < order; ++k) acc += m[r][k] * m[k][c];
+                for (int j = 0; j < order; ++j) acc += m[r][j] * m[j][c];
+                if (!(std::fabs(acc) < 1e150)) return IirPlan{false, 0u, 0u};  // also for NaN
                 t[r][c] = acc;
+                row += std::fabs(acc);
             }
+            worst_row = std::fmax(worst_row, row);
+        }
         for (int r = 0; r < order; ++r)
-            for (int c = 0; c < order; ++c) {
-                if (!(std::fabs(t[r][c]) < 1e150)) return false;  // also false for NaN
-                m[r][c] = t[r][c];
-            }
+            for (int c = 0; c < order; ++c) m[r][c] = t[r][c];
+        if (worst_row <= small) {
+            if (k >= 4 && k < 4 + kIirLevels) plan.lane_plain |= 1u << (k - 4);
+            if (k >= 4 + kIirLevels) plan.tile_plain |= 1u << (k - 4 - kIirLevels);
+        }
     }
-    return true;
+    return plan;
 }
 
 #define DSPX_IIR_DISPATCH(call)       \
