@@ -49,6 +49,9 @@ SIGNATURES = {
     "dspx_lfilter_f64_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
                                        C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
                                        C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t, C.c_uint, C.c_void_p]),
+    "dspx_lfilter_f64_dev_noalloc": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                               C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                               C.c_size_t, C.c_size_t, C.c_uint, C.c_void_p]),
     "dspx_fir_plan": (C.c_long, [C.c_size_t, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t]),
     "dspx_fir_f64_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
                                    C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_uint, C.c_void_p]),

@@ -101,8 +101,8 @@ def lfilter_iir_stream(b, a, xhist, yhist, x, exact: bool = False) -> np.ndarray
     return y.reshape(x.shape)
 
 
-def lfilter_iir_device(b, a, x, out=None, xhist=None, yhist=None, exact: bool = False, mfma=None):
-    """dspx_lfilter_f64_dev on torch CUDA tensors: `b` (device taps), `a` (host coefficients), x/out
+def lfilter_iir_device(b, a, x, out=None, xhist=None, yhist=None, exact: bool = False, mfma=None, noalloc: bool = False):
+    """dspx_lfilter_f64_dev (noalloc: dspx_lfilter_f64_dev_noalloc) on torch CUDA tensors: `b` (device taps), `a` (host coefficients), x/out
     [nchan, n] or [n]; xhist / yhist: the samples / outputs that precede the call, oldest first."""
     import torch
 
@@ -124,6 +124,11 @@ def lfilter_iir_device(b, a, x, out=None, xhist=None, yhist=None, exact: bool = 
 
     xh, xhs = hist_args(xhist, max(b.numel() - 1, 0))
     yh, yhs = hist_args(yhist, max(a.size - 1, 0))
+    if noalloc:   # the library's static scratch instead of a workspace; `out` must be given for the call to allocate nothing
+        check(lib().dspx_lfilter_f64_dev_noalloc(b.data_ptr(), b.numel(), a.ctypes.data, a.size, x2.data_ptr(), x2.stride(0),
+                                                 xh, xhs, yh, yhs, o2.data_ptr(), o2.stride(0), nchan, n,
+                                                 _flags(exact, mfma), _stream_ptr()))
+        return out
     need = int(lib().dspx_lfilter_workspace_bytes(a.size, nchan, n))
     work = torch.empty(max(need, 1), dtype=torch.uint8, device=x.device)
     check(lib().dspx_lfilter_f64_dev(b.data_ptr(), b.numel(), a.ctypes.data, a.size, x2.data_ptr(), x2.stride(0), xh, xhs,

@@ -116,6 +116,18 @@ size_t tail_workspace_bytes(const Tail& t, size_t nchan, size_t n) {
     return t.order && t.scan ? dspx::iir_workspace_bytes(nchan, n, t.order) : 0;
 }
 
+// Workspace the block-parallel tail needs for a call of `nchan` channels x `n` samples: launch_tail() cuts the
+// channels into launches that reuse one workspace, so the need is that of the most demanding launch (the last
+// one can be the only one with too few channels for the walk kernel, which is the one that needs no tile states).
+size_t scan_workspace_bytes(int order, size_t nchan, size_t n) {
+    const size_t tiles = (n + dspx::kIirTile - 1) / dspx::kIirTile;
+    const size_t per_launch = std::max<size_t>(1, kMaxGrid / std::max<size_t>(tiles, 1));
+    size_t need = 0;
+    if (nchan >= per_launch) need = dspx::iir_workspace_bytes(per_launch, n, order);
+    if (nchan % per_launch) need = std::max(need, dspx::iir_workspace_bytes(nchan % per_launch, n, order));
+    return need;
+}
+
 // Applies the tail in place to d_y (which holds the FIR part).  d_state: per channel the `order` outputs
 // that precede y[0], oldest first (nullable).  d_work: tail_workspace_bytes() for the channels of one launch.
 // True when the numerator is short enough for the tail kernels to compute the FIR part themselves.
@@ -581,6 +593,75 @@ int host_path(const double* taps, size_t ntaps, const double* hist0, const doubl
     return DSPX_OK;
 }
 
+
+// Body of dspx_lfilter_f64_dev and dspx_lfilter_f64_dev_noalloc: the FIR part (or nothing, when the tail kernels
+// compute it themselves), then the recursive tail in place on d_y with `d_work` as its workspace.  Allocates nothing.
+int lfilter_dev(const double* d_b, size_t nb, const double* a, size_t na, const double* d_x, size_t x_stride,
+                const double* d_xhist, size_t xhist_stride, const double* d_yhist, size_t yhist_stride, double* d_y,
+                size_t y_stride, size_t nchan, size_t n, void* d_work, size_t work_bytes, const char* work_name,
+                unsigned flags, void* stream) {
+    Tail tail;
+    if (int rc = dspx::check_flags(flags)) return rc;
+    if (int rc = make_tail(a, na, flags, tail)) return rc;
+    // everything that can be refused is refused before the first launch
+    const size_t need = tail.order && tail.scan && nchan && n ? scan_workspace_bytes(tail.order, nchan, n) : 0;
+    if (need && (!d_work || work_bytes < need))
+        return fail(DSPX_ERR_INVALID, "the recursive tail needs %zu bytes of scratch for %zu channel(s) x %zu samples, "
+                    "%s holds %zu", need, nchan, n, work_name, d_work ? work_bytes : (size_t)0);
+    if (tail.order && d_yhist && nchan > 1 && yhist_stride < (size_t)tail.order)
+        return fail(DSPX_ERR_INVALID, "yhist_stride (%zu) < na-1", yhist_stride);
+    const bool fused = tail_fuses_fir(tail, nb, flags);
+    if (fused) {  // the checks dspx_fir_f64_dev would make; the tail kernels read x themselves
+        if (int rc = check_common(d_b, nb, d_x, d_y, nchan, n, flags)) return rc;
+        if (nchan > 1 && (x_stride < n || y_stride < n))
+            return fail(DSPX_ERR_INVALID, "channel stride smaller than n (%zu): x %zu, y %zu", n, x_stride, y_stride);
+        if (d_xhist && nchan > 1 && nb > 1 && xhist_stride < nb - 1)
+            return fail(DSPX_ERR_INVALID, "hist_stride (%zu) < ntaps-1", xhist_stride);
+        if (nchan && n && ranges_overlap(d_x, ((nchan - 1) * x_stride + n) * sizeof(double), d_y,
+                                         ((nchan - 1) * y_stride + n) * sizeof(double)))
+            return fail(DSPX_ERR_INVALID, "d_x and d_y overlap");
+    } else if (int rc = dspx_fir_f64_dev(d_b, nb, d_x, x_stride, d_xhist, xhist_stride, d_y, y_stride, nchan, n, flags,
+                                         stream)) {
+        return rc;
+    }
+    if (tail.order == 0 || nchan == 0 || n == 0) return DSPX_OK;
+    const dspx::IirFront front = make_front(d_b, nb, d_x, x_stride, d_xhist, xhist_stride);
+    return launch_tail(tail, d_y, y_stride, d_yhist, yhist_stride, nchan, n, d_work, static_cast<hipStream_t>(stream),
+                       fused ? &front : nullptr);
+}
+
+// ---------------------------------------------------------------------------------
+// Scratch of dspx_lfilter_f64_dev_noalloc: the workspace of the block-parallel tail (matrix powers + one state per
+// tile) in a device array that is part of the library's code object, so that entry point never allocates.  Every
+// device the library runs on holds its own copy at its own address for the life of the process.  `scratch` is a
+// host-side stand-in for the symbol, not a device address: host code only ever uses the address
+// hipGetSymbolAddress returned for the current device.
+constexpr size_t kStaticScratchBytes = DSPX_NOALLOC_SCRATCH_BYTES;
+static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
+
+constexpr int kMaxScratchDevices = 64;
+std::mutex g_scratch_mu;
+void* g_scratch_ptr[kMaxScratchDevices] = {};
+
+// The current device's copy of `scratch` (looked up once per device, on the first call there).
+int static_scratch(void** out) {
+    int dev = -1;
+    DSPX_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= kMaxScratchDevices)
+        return fail(DSPX_ERR_INVALID, "device index %d outside the %d devices the static scratch is kept for", dev,
+                    kMaxScratchDevices);
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    if (!g_scratch_ptr[dev]) {
+        void* p = nullptr;
+        DSPX_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        if (!p || (reinterpret_cast<uintptr_t>(p) & 255u))
+            return fail(DSPX_ERR_HIP, "hipGetSymbolAddress(scratch) returned %p on device %d", p, dev);
+        g_scratch_ptr[dev] = p;
+    }
+    *out = g_scratch_ptr[dev];
+    return DSPX_OK;
+}
+
 }  // namespace
 
 namespace dspx {
@@ -747,42 +828,27 @@ int dspx_lfilter_f64_stream(const double* b, size_t nb, const double* a, size_t 
 
 size_t dspx_lfilter_workspace_bytes(size_t na, size_t nchan, size_t n) {
     if (na <= 1 || na - 1 > (size_t)dspx::kIirMaxOrder) return 0;
-    const size_t tiles = (n + dspx::kIirTile - 1) / dspx::kIirTile;
-    const size_t per_launch = std::min(nchan, std::max<size_t>(1, kMaxGrid / std::max<size_t>(tiles, 1)));
-    return dspx::iir_workspace_bytes(per_launch, n, (int)(na - 1));
+    return scan_workspace_bytes((int)(na - 1), nchan, n);
 }
 
 int dspx_lfilter_f64_dev(const double* d_b, size_t nb, const double* a, size_t na, const double* d_x, size_t x_stride,
                          const double* d_xhist, size_t xhist_stride, const double* d_yhist, size_t yhist_stride,
                          double* d_y, size_t y_stride, size_t nchan, size_t n, void* d_work, size_t work_bytes,
                          unsigned flags, void* stream) {
-    Tail tail;
-    if (int rc = dspx::check_flags(flags)) return rc;
-    if (int rc = make_tail(a, na, flags, tail)) return rc;
-    const bool fused = tail_fuses_fir(tail, nb, flags);
-    if (fused) {  // the checks dspx_fir_f64_dev would make; the tail kernels read x themselves
-        if (int rc = check_common(d_b, nb, d_x, d_y, nchan, n, flags)) return rc;
-        if (nchan > 1 && (x_stride < n || y_stride < n))
-            return fail(DSPX_ERR_INVALID, "channel stride smaller than n (%zu): x %zu, y %zu", n, x_stride, y_stride);
-        if (d_xhist && nchan > 1 && nb > 1 && xhist_stride < nb - 1)
-            return fail(DSPX_ERR_INVALID, "hist_stride (%zu) < ntaps-1", xhist_stride);
-        if (nchan && n && ranges_overlap(d_x, ((nchan - 1) * x_stride + n) * sizeof(double), d_y,
-                                         ((nchan - 1) * y_stride + n) * sizeof(double)))
-            return fail(DSPX_ERR_INVALID, "d_x and d_y overlap");
-    } else if (int rc = dspx_fir_f64_dev(d_b, nb, d_x, x_stride, d_xhist, xhist_stride, d_y, y_stride, nchan, n, flags,
-                                         stream)) {
-        return rc;
-    }
-    if (tail.order == 0 || nchan == 0 || n == 0) return DSPX_OK;
-    if (d_yhist && nchan > 1 && yhist_stride < (size_t)tail.order)
-        return fail(DSPX_ERR_INVALID, "yhist_stride (%zu) < na-1", yhist_stride);
-    const size_t need = tail.scan ? dspx_lfilter_workspace_bytes(na, nchan, n) : 0;
-    if (need && (!d_work || work_bytes < need))
-        return fail(DSPX_ERR_INVALID, "workspace of %zu bytes needed (dspx_lfilter_workspace_bytes), got %zu", need,
-                    d_work ? work_bytes : (size_t)0);
-    const dspx::IirFront front = make_front(d_b, nb, d_x, x_stride, d_xhist, xhist_stride);
-    return launch_tail(tail, d_y, y_stride, d_yhist, yhist_stride, nchan, n, d_work, static_cast<hipStream_t>(stream),
-                       fused ? &front : nullptr);
+    return lfilter_dev(d_b, nb, a, na, d_x, x_stride, d_xhist, xhist_stride, d_yhist, yhist_stride, d_y, y_stride, nchan,
+                       n, d_work, work_bytes, "the workspace (dspx_lfilter_workspace_bytes)", flags, stream);
+}
+
+int dspx_lfilter_f64_dev_noalloc(const double* d_b, size_t nb, const double* a, size_t na, const double* d_x,
+                                 size_t x_stride, const double* d_xhist, size_t xhist_stride, const double* d_yhist,
+                                 size_t yhist_stride, double* d_y, size_t y_stride, size_t nchan, size_t n,
+                                 unsigned flags, void* stream) {
+    void* work = nullptr;
+    if (int rc = static_scratch(&work)) return rc;
+    return lfilter_dev(d_b, nb, a, na, d_x, x_stride, d_xhist, xhist_stride, d_yhist, yhist_stride, d_y, y_stride, nchan,
+                       n, work, kStaticScratchBytes,
+                       "the library's static scratch (DSPX_NOALLOC_SCRATCH_BYTES); use dspx_lfilter_f64_dev with a workspace",
+                       flags, stream);
 }
 
 long dspx_fir_plan(size_t nchan, size_t n, int ngpus, dspx_piece* out, size_t cap) {

@@ -56,8 +56,8 @@ struct IirShape {
     unsigned lane_plain, tile_plain;  // bit d: level d of that scan may use plain products (IirPlan)
 };
 
-// Bytes of device workspace the scan path needs for `nchan` channels of `n` samples (tables + one
-// state per tile).
+// Bytes of device workspace one launch of the scan path needs for `nchan` channels of `n` samples: the
+// tables, plus one state per tile unless the launch has enough channels for one workgroup to walk each.
 size_t iir_workspace_bytes(size_t nchan, size_t n, int order);
 
 // What the host learns from the matrix powers (computed in double, as the device computes them in

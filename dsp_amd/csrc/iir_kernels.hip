@@ -557,6 +557,7 @@ constexpr size_t kTablesBytes = (sizeof(IirTables) + 255) & ~size_t(255);
 }  // namespace
 
 size_t iir_workspace_bytes(size_t nchan, size_t n, int order) {
+    if (nchan >= kWalkMinChans) return kTablesBytes;  // iir_walk_kernel carries the state itself: no tile states
     const size_t tiles = (n + kIirTile - 1) / kIirTile;
     return kTablesBytes + nchan * tiles * (size_t)order * sizeof(double);
 }

@@ -140,6 +140,22 @@ DSPX_API int dspx_lfilter_f64_dev(const double* d_b, size_t nb, const double* a,
                                   size_t yhist_stride, double* d_y, size_t y_stride, size_t nchan, size_t n,
                                   void* d_work, size_t work_bytes, unsigned flags, void* stream);
 
+/* dspx_lfilter_f64_dev for callers that cannot allocate device memory or bring a workspace (code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc).  It has no counterpart in the reference.  Same
+ * arguments, kernels and results (bit for bit) as dspx_lfilter_f64_dev, minus d_work / work_bytes: the tail's scratch
+ * (matrix powers, one state per 4096-sample tile of every channel) lives in a DSPX_NOALLOC_SCRATCH_BYTES array inside
+ * the library's device code, one copy per GPU for the life of the process.  The call itself makes no hipMalloc /
+ * hipFree and uses no allocating library routine.  A call whose tail needs more (dspx_lfilter_workspace_bytes(na,
+ * nchan, n) > DSPX_NOALLOC_SCRATCH_BYTES; launches of 1024 channels or more need only 20 KiB whatever n is) returns
+ * DSPX_ERR_INVALID before anything is launched.  All calls on one GPU share that GPU's array: calls that overlap in
+ * time on one GPU (different streams or threads) race; calls on one stream, or on different GPUs, do not.  Nothing in
+ * the array has to start at zero (every call rewrites what it reads). */
+#define DSPX_NOALLOC_SCRATCH_BYTES ((size_t)16 << 20)
+DSPX_API int dspx_lfilter_f64_dev_noalloc(const double* d_b, size_t nb, const double* a, size_t na, const double* d_x,
+                                          size_t x_stride, const double* d_xhist, size_t xhist_stride,
+                                          const double* d_yhist, size_t yhist_stride, double* d_y, size_t y_stride,
+                                          size_t nchan, size_t n, unsigned flags, void* stream);
+
 /* The sharding plan dspx_fir_f64_multi executes, exposed so that it can be inspected and
  * tested without GPUs: piece i covers channels [chan, chan + nchan) x samples
  * [start, start + len) and is assigned to `device`; the pieces of one device are staged
