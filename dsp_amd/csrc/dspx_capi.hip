@@ -236,6 +236,8 @@ std::vector<std::vector<Piece>> make_plan(size_t nchan, size_t n, int G) {
 struct Slot {
     double *pin_in = nullptr, *pin_out = nullptr, *d_in = nullptr, *d_out = nullptr;
     void* d_work = nullptr;          // workspace of the recursive tail
+    double* d_tail = nullptr;        // recursive filters: the last outputs of the slot's piece, read by the piece
+                                     // that continues its channel (kIirMaxOrder doubles)
     size_t in_cap = 0, out_cap = 0;  // doubles
     size_t work_cap = 0;             // bytes
     hipStream_t stream = nullptr;
@@ -248,7 +250,6 @@ constexpr int kSlots = 8;
 // small filter).  One call uses an engine exclusively; concurrent calls on a device get engines of their own.
 struct Engine {
     int device = -1;
-    double* d_tail_state = nullptr;  // the last outputs of a piece, for the piece that continues its channel
     Slot slots[kSlots];
 };
 
@@ -269,8 +270,8 @@ void destroy_engine(Engine* e) {
         if (s.d_in) (void)hipFree(s.d_in);
         if (s.d_out) (void)hipFree(s.d_out);
         if (s.d_work) (void)hipFree(s.d_work);
+        if (s.d_tail) (void)hipFree(s.d_tail);
     }
-    if (e->d_tail_state) (void)hipFree(e->d_tail_state);
     (void)hipSetDevice(cur);
     delete e;
 }
@@ -292,8 +293,8 @@ int acquire_engine(int device, Engine** out) {
         for (auto& s : e->slots) {
             DSPX_HIP(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
             DSPX_HIP(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+            DSPX_HIP(hipMalloc((void**)&s.d_tail, dspx::kIirMaxOrder * sizeof(double)));
         }
-        DSPX_HIP(hipMalloc((void**)&e->d_tail_state, dspx::kIirMaxOrder * sizeof(double)));
         return DSPX_OK;
     };
     if (int rc = body()) {
@@ -450,20 +451,26 @@ struct Pipeline {
                 return lrc;
         if (tail->order) {
             // a piece that continues a channel starts from the last outputs of the piece before it, which
-            // runs on another stream: wait for it (pieces of a channel are issued in order by one thread)
+            // runs on another stream and left them in its own slot: wait for it (such pieces are issued in
+            // order by one thread)
             const double* d_state = with_y0 ? s.d_in + y0_off : nullptr;
             if (p.s0 > 0) {
-                DSPX_HIP(hipStreamWaitEvent(s.stream, eng->slots[(i - 1) % kSlots].done, 0));
-                d_state = eng->d_tail_state;
+                const Slot& before = eng->slots[(i - 1) % kSlots];
+                DSPX_HIP(hipStreamWaitEvent(s.stream, before.done, 0));
+                d_state = before.d_tail;
             }
             const dspx::IirFront front = make_front(s.d_in, ntaps, d_rows + g.hl_pad, g.in_pitch, d_xhist, g.in_pitch);
             if (int trc = launch_tail(*tail, s.d_out, g.out_pitch, d_state, (size_t)tail->order, p.cnt, p.len, s.d_work,
                                       s.stream, fused ? &front : nullptr))
                 return trc;
             const bool continues = i + 1 < pieces->size() && (*pieces)[i + 1].s0 > 0;
-            if (continues)  // cnt == 1 and len >= order here
-                DSPX_HIP(hipMemcpyAsync(eng->d_tail_state, s.d_out + (p.len - (size_t)tail->order),
+            if (continues) {  // cnt == 1 and len >= order here
+                // the slot's buffer was last read by the piece after this slot's previous piece (piece
+                // i + 1 - kSlots, whose event its slot still holds: piece i + 1 is not issued yet)
+                if (i >= (size_t)kSlots) DSPX_HIP(hipStreamWaitEvent(s.stream, eng->slots[(i + 1) % kSlots].done, 0));
+                DSPX_HIP(hipMemcpyAsync(s.d_tail, s.d_out + (p.len - (size_t)tail->order),
                                         (size_t)tail->order * sizeof(double), hipMemcpyDeviceToDevice, s.stream));
+            }
         }
         DSPX_HIP(hipMemcpyAsync(s.pin_out, s.d_out, g.out_pitch * p.cnt * sizeof(double), hipMemcpyDeviceToHost,
                                 s.stream));
@@ -524,11 +531,17 @@ int run_pipeline(Pipeline& pl, size_t max_threads) {
         if (pl.tail->order)  // pieces that continue a channel must be issued in order, by one thread
             for (const Piece& p : pieces)
                 if (p.s0 > 0) producers = 1;
-        std::vector<std::thread> workers;
-        for (size_t k = 0; k < nthreads; ++k) workers.emplace_back([&pl, k, nthreads] { pl.consumer(k, nthreads); });
-        for (size_t k = 1; k < producers; ++k) workers.emplace_back([&pl, k, producers] { pl.producer(k, producers); });
-        pl.producer(0, producers);
-        for (auto& w : workers) w.join();
+        dspx::Joiner workers;
+        try {
+            for (size_t k = 0; k < nthreads; ++k)
+                workers.threads.emplace_back([&pl, k, nthreads] { pl.consumer(k, nthreads); });
+            for (size_t k = 1; k < producers; ++k)
+                workers.threads.emplace_back([&pl, k, producers] { pl.producer(k, producers); });
+            pl.producer(0, producers);
+        } catch (const std::exception& e) {  // a thread could not start: the ones that did see the failure and leave
+            pl.set_error(fail(DSPX_ERR_HOST, "staging threads: %s", e.what()));
+        }
+        workers.join();
         if (pl.rc != DSPX_OK) g_last_error = pl.msg;
         return pl.rc;
     };
@@ -554,11 +567,11 @@ int run_device(int device, const double* taps, size_t ntaps, const double* hist0
     Engine* eng = nullptr;
     if (int rc = acquire_engine(device, &eng)) return rc;
     Pipeline pl(device, eng, taps, hist0, x, y, ntaps, stride, flags, &pieces, &tail);
-    return run_pipeline(pl, max_threads);
+    return run_pipeline(pl, max_threads);  // `device` is a physical device (see dspx::physical_device)
 }
 
-int host_path(const double* taps, size_t ntaps, const double* hist0, const double* x, double* y, size_t nchan,
-              size_t n, size_t stride, int ngpus, unsigned flags, const Tail& tail = Tail{}) {
+int host_path_body(const double* taps, size_t ntaps, const double* hist0, const double* x, double* y, size_t nchan,
+                   size_t n, size_t stride, int ngpus, unsigned flags, const Tail& tail) {
     if (int rc = check_common(taps, ntaps, x, y, nchan, n, flags)) return rc;
     if (nchan == 0 || n == 0) return DSPX_OK;
     if (stride < n) return fail(DSPX_ERR_INVALID, "stride (%zu) < n (%zu)", stride, n);
@@ -574,25 +587,36 @@ int host_path(const double* taps, size_t ntaps, const double* hist0, const doubl
         return run_device(cur, taps, ntaps, hist0, x, y, stride, pieces, flags, 4, tail);
     }
     int G = ngpus == 0 ? ndev : ngpus;
-    if (G > ndev) return fail(DSPX_ERR_INVALID, "ngpus (%d) exceeds visible devices (%d)", G, ndev);
+    if (G > dspx::logical_device_limit(ndev))
+        return fail(DSPX_ERR_INVALID, "ngpus (%d) exceeds visible devices (%d)", G, ndev);
     // a recursive filter's state is a serial dependence along a channel: such filters shard by channels only
     if (tail.order && nchan < (size_t)G) G = (int)nchan;
     const std::vector<std::vector<Piece>> plan = make_plan(nchan, n, G);
     std::vector<int> rcs(G, DSPX_OK);
     std::vector<std::string> msgs(G);
-    std::vector<std::thread> workers;
-    for (int g = 0; g < G; ++g)
-        workers.emplace_back([&, g] {
-            rcs[g] = run_device(g, taps, ntaps, hist0, x, y, stride, plan[g], flags, G > 2 ? 1 : 2, tail);
-            if (rcs[g] != DSPX_OK) msgs[g] = g_last_error;
-        });
-    for (auto& w : workers) w.join();
+    {
+        dspx::Joiner workers;  // joins the threads that did start if one cannot (the exception goes on to the entry point)
+        for (int g = 0; g < G; ++g)
+            workers.threads.emplace_back([&, g] {
+                rcs[g] = dspx::guarded([&] {
+                    return run_device(dspx::physical_device(g, ndev), taps, ntaps, hist0, x, y, stride, plan[g], flags,
+                                      G > 2 ? 1 : 2, tail);
+                });
+                if (rcs[g] != DSPX_OK) msgs[g] = g_last_error;
+            });
+    }
     (void)hipSetDevice(cur);
     for (int g = 0; g < G; ++g)
         if (rcs[g] != DSPX_OK) return fail(rcs[g], "device %d: %s", g, msgs[g].c_str());
     return DSPX_OK;
 }
 
+
+// The host-pointer entry points: no C++ exception (allocation, thread creation) crosses the C ABI.
+int host_path(const double* taps, size_t ntaps, const double* hist0, const double* x, double* y, size_t nchan, size_t n,
+              size_t stride, int ngpus, unsigned flags, const Tail& tail = Tail{}) {
+    return dspx::guarded([&] { return host_path_body(taps, ntaps, hist0, x, y, nchan, n, stride, ngpus, flags, tail); });
+}
 
 // Body of dspx_lfilter_f64_dev and dspx_lfilter_f64_dev_noalloc: the FIR part (or nothing, when the tail kernels
 // compute it themselves), then the recursive tail in place on d_y with `d_work` as its workspace.  Allocates nothing.
@@ -715,31 +739,28 @@ const char* dspx_status_string(int status) {
     case DSPX_ERR_HIP: return "HIP runtime error";
     case DSPX_ERR_NOMEM: return "out of device memory";
     case DSPX_ERR_DOMAIN: return "value outside the supported domain";
+    case DSPX_ERR_HOST: return "host-side failure inside the library";
     default: return "unknown status";
     }
 }
 
 int dspx_firwin_f64(size_t numtaps, const double* cutoffs, size_t ncutoffs, int pass_zero, int scale, double* out) {
     if ((ncutoffs && !cutoffs) || (numtaps && !out)) return fail(DSPX_ERR_INVALID, "NULL pointer");
-    try {
+    return dspx::guarded([&] {  // the reference's std::invalid_argument becomes DSPX_ERR_INVALID with its message
         const std::vector<double> c(cutoffs, cutoffs + ncutoffs);
         const std::vector<double> h = dsp::firwin<double>(numtaps, c, pass_zero != 0, scale != 0);
         std::copy(h.begin(), h.end(), out);
-    } catch (const std::invalid_argument& e) {
-        return fail(DSPX_ERR_INVALID, "%s", e.what());
-    }
-    return DSPX_OK;
+        return (int)DSPX_OK;
+    });
 }
 
 int dspx_hamming_window_f64(size_t width, double alpha, int sym, double* out) {
     if (width && !out) return fail(DSPX_ERR_INVALID, "NULL pointer");
-    try {
+    return dspx::guarded([&] {
         const std::vector<double> w = dsp::hamming_window<double>(width, alpha, sym != 0);
         std::copy(w.begin(), w.end(), out);
-    } catch (const std::invalid_argument& e) {
-        return fail(DSPX_ERR_INVALID, "%s", e.what());
-    }
-    return DSPX_OK;
+        return (int)DSPX_OK;
+    });
 }
 
 double dspx_sinc_f64(double x) { return dsp::sinc<double>(x); }
@@ -854,14 +875,19 @@ int dspx_lfilter_f64_dev_noalloc(const double* d_b, size_t nb, const double* a, 
 long dspx_fir_plan(size_t nchan, size_t n, int ngpus, dspx_piece* out, size_t cap) {
     if (ngpus < 1) return fail(DSPX_ERR_INVALID, "ngpus must be >= 1");
     if (cap && !out) return fail(DSPX_ERR_INVALID, "out is NULL");
-    const auto plan = make_plan(nchan, n, ngpus);
-    size_t k = 0;
-    for (int g = 0; g < ngpus; ++g)
-        for (const Piece& p : plan[g]) {
-            if (k < cap) out[k] = dspx_piece{g, p.c, p.cnt, p.s0, p.len};
-            ++k;
-        }
-    return (long)k;
+    long total = 0;
+    const int rc = dspx::guarded([&] {
+        const auto plan = make_plan(nchan, n, ngpus);
+        size_t k = 0;
+        for (int g = 0; g < ngpus; ++g)
+            for (const Piece& p : plan[g]) {
+                if (k < cap) out[k] = dspx_piece{g, p.c, p.cnt, p.s0, p.len};
+                ++k;
+            }
+        total = (long)k;
+        return (int)DSPX_OK;
+    });
+    return rc == DSPX_OK ? total : (long)rc;
 }
 
 int dspx_fir_f64_dev(const double* d_taps, size_t ntaps, const double* d_x, size_t x_stride, const double* d_hist,

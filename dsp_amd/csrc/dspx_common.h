@@ -4,7 +4,12 @@
 
 #include <cstddef>
 #include <cstdint>
+#include <cstdlib>
+#include <new>
+#include <stdexcept>
 #include <string>
+#include <thread>
+#include <vector>
 
 #include "dspx.h"
 
@@ -49,6 +54,44 @@ int download_rows(int device, const double* d_src, size_t src_pitch, size_t rows
                   size_t dst_stride, const size_t* row_map);
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// Test knob for machines with fewer GPUs than a sharding is meant for: with DSPX_ALIAS_DEVICES=1 in the
+// environment the multi-device entry points accept any ngpus up to kMaxAliasedDevices and run logical device g
+// on physical device g % (visible devices), each logical device with its own thread, staging engine and plan,
+// exactly as on a machine that has them.  Results do not depend on it (nor on ngpus at all).
+constexpr int kMaxAliasedDevices = 16;
+inline bool devices_aliased() {
+    const char* e = std::getenv("DSPX_ALIAS_DEVICES");
+    return e && e[0] == '1' && e[1] == '\0';
+}
+inline int logical_device_limit(int visible) { return devices_aliased() ? kMaxAliasedDevices : visible; }
+inline int physical_device(int logical, int visible) { return devices_aliased() && visible > 0 ? logical % visible : logical; }
+
+// Threads that are joined when the owner goes out of scope, whichever way it leaves.
+struct Joiner {
+    std::vector<std::thread> threads;
+    void join() {
+        for (auto& t : threads)
+            if (t.joinable()) t.join();
+        threads.clear();
+    }
+    ~Joiner() { join(); }
+};
+
+// Runs the body of an extern "C" entry point: no C++ exception leaves the library.
+template <class F> int guarded(F&& body) noexcept {
+    try {
+        return body();
+    } catch (const std::bad_alloc&) {
+        return fail(DSPX_ERR_NOMEM, "out of host memory");
+    } catch (const std::invalid_argument& e) {
+        return fail(DSPX_ERR_INVALID, "%s", e.what());
+    } catch (const std::exception& e) {
+        return fail(DSPX_ERR_HOST, "%s", e.what());
+    } catch (...) {
+        return fail(DSPX_ERR_HOST, "unknown C++ exception");
+    }
+}
 
 }  // namespace dspx
 

@@ -264,19 +264,23 @@ int cwt_host(const double* signal, size_t n, const double* scales, size_t nscale
         return run_cwt_device(cur, t, psi, all, signal, n, result, flags);
     }
     const int G = ngpus == 0 ? ndev : ngpus;
-    if (G > ndev) return fail(DSPX_ERR_INVALID, "ngpus (%d) exceeds visible devices (%d)", G, ndev);
+    if (G > dspx::logical_device_limit(ndev))
+        return fail(DSPX_ERR_INVALID, "ngpus (%d) exceeds visible devices (%d)", G, ndev);
     const std::vector<int> dev = assign_rows(t, G);
     std::vector<std::vector<size_t>> picks(G);
     for (size_t r = 0; r < dev.size(); ++r) picks[dev[r]].push_back(r);
     std::vector<int> rcs(G, DSPX_OK);
     std::vector<std::string> msgs(G);
-    std::vector<std::thread> workers;
-    for (int g = 0; g < G; ++g)
-        workers.emplace_back([&, g] {
-            rcs[g] = run_cwt_device(g, t, psi, picks[g], signal, n, result, flags);
-            if (rcs[g] != DSPX_OK) msgs[g] = dspx::g_last_error;
-        });
-    for (auto& w : workers) w.join();
+    {
+        dspx::Joiner workers;  // joins the threads that did start if one cannot
+        for (int g = 0; g < G; ++g)
+            workers.threads.emplace_back([&, g] {
+                rcs[g] = dspx::guarded([&] {
+                    return run_cwt_device(dspx::physical_device(g, ndev), t, psi, picks[g], signal, n, result, flags);
+                });
+                if (rcs[g] != DSPX_OK) msgs[g] = dspx::g_last_error;
+            });
+    }
     (void)hipSetDevice(cur);
     for (int g = 0; g < G; ++g)
         if (rcs[g] != DSPX_OK) return fail(rcs[g], "device %d: %s", g, msgs[g].c_str());
@@ -289,38 +293,38 @@ extern "C" {
 
 int dspx_integrate_wavelet_morlet_f64(size_t precision, double lower, double upper, double* psi, double* x) {
     if (!psi || !x) return fail(DSPX_ERR_INVALID, "NULL pointer");
-    try {
+    return dspx::guarded([&] {
         const auto [p, t] = dsp::integrate_wavelet<double>(dsp::cwt_wavelet_t::MORLET, precision, lower, upper);
         std::copy(p.begin(), p.end(), psi);
         std::copy(t.begin(), t.end(), x);
-    } catch (const std::invalid_argument& e) {
-        return fail(DSPX_ERR_INVALID, "%s", e.what());
-    }
-    return DSPX_OK;
+        return (int)DSPX_OK;
+    });
 }
 
 int dspx_cwt_f64(const double* signal, size_t n, const double* scales, size_t nscales, const double* psi, size_t npsi,
                  const double* wx, size_t nx, double* result, unsigned flags) {
-    return cwt_host(signal, n, scales, nscales, psi, npsi, wx, nx, result, -1, flags);
+    return dspx::guarded([&] { return cwt_host(signal, n, scales, nscales, psi, npsi, wx, nx, result, -1, flags); });
 }
 
 int dspx_cwt_f64_multi(const double* signal, size_t n, const double* scales, size_t nscales, const double* psi,
                        size_t npsi, const double* wx, size_t nx, double* result, int ngpus, unsigned flags) {
     if (ngpus < 0) return fail(DSPX_ERR_INVALID, "ngpus must be >= 0");
-    return cwt_host(signal, n, scales, nscales, psi, npsi, wx, nx, result, ngpus, flags);
+    return dspx::guarded([&] { return cwt_host(signal, n, scales, nscales, psi, npsi, wx, nx, result, ngpus, flags); });
 }
 
 int dspx_cwt_plan(const double* scales, size_t nscales, size_t npsi, const double* wx, size_t nx, int ngpus,
                   int* device_of_row, size_t* ntaps_of_row) {
     if (ngpus < 1) return fail(DSPX_ERR_INVALID, "ngpus must be >= 1");
-    Tables t;
-    if (int rc = build_tables(scales, nscales, npsi, wx, nx, 0, false, t)) return rc;
-    const std::vector<int> dev = assign_rows(t, ngpus);
-    for (size_t r = 0; r < t.rows.size(); ++r) {
-        if (device_of_row) device_of_row[r] = dev[r];
-        if (ntaps_of_row) ntaps_of_row[r] = t.rows[r].index.size();
-    }
-    return DSPX_OK;
+    return dspx::guarded([&] {
+        Tables t;
+        if (int rc = build_tables(scales, nscales, npsi, wx, nx, 0, false, t)) return rc;
+        const std::vector<int> dev = assign_rows(t, ngpus);
+        for (size_t r = 0; r < t.rows.size(); ++r) {
+            if (device_of_row) device_of_row[r] = dev[r];
+            if (ntaps_of_row) ntaps_of_row[r] = t.rows[r].index.size();
+        }
+        return (int)DSPX_OK;
+    });
 }
 
 int dspx_cwt_bank_create(const double* scales, size_t nscales, const double* psi, size_t npsi, const double* wx,
@@ -328,13 +332,15 @@ int dspx_cwt_bank_create(const double* scales, size_t nscales, const double* psi
     if (!bank) return fail(DSPX_ERR_INVALID, "bank is NULL");
     if (!psi) return fail(DSPX_ERR_INVALID, "wavelet_psi is NULL");
     *bank = nullptr;
-    Tables t;
-    if (int rc = build_tables(scales, nscales, npsi, wx, nx, 0, false, t)) return rc;
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(DSPX_ERR_NO_DEVICE, "no HIP device");
-    std::vector<size_t> all(t.rows.size());
-    std::iota(all.begin(), all.end(), size_t(0));
-    return make_bank(t, psi, all, all, bank);
+    return dspx::guarded([&] {
+        Tables t;
+        if (int rc = build_tables(scales, nscales, npsi, wx, nx, 0, false, t)) return rc;
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(DSPX_ERR_NO_DEVICE, "no HIP device");
+        std::vector<size_t> all(t.rows.size());
+        std::iota(all.begin(), all.end(), size_t(0));
+        return make_bank(t, psi, all, all, bank);
+    });
 }
 
 size_t dspx_cwt_bank_rows(const dspx_cwt_bank* bank) { return bank ? bank->nrows : 0; }

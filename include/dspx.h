@@ -33,8 +33,9 @@ typedef enum dspx_status {
     DSPX_ERR_INVALID = -1,   /* bad pointer / size / stride / overlapping buffers */
     DSPX_ERR_NO_DEVICE = -2, /* no usable gfx950 device */
     DSPX_ERR_HIP = -3,       /* a HIP runtime call failed; see dspx_last_error() */
-    DSPX_ERR_NOMEM = -4,     /* device allocation failed */
-    DSPX_ERR_DOMAIN = -5     /* where the reference throws std::runtime_error (e.g. a wavelet scale too large) */
+    DSPX_ERR_NOMEM = -4,     /* a device or host allocation failed */
+    DSPX_ERR_DOMAIN = -5,    /* where the reference throws std::runtime_error (e.g. a wavelet scale too large) */
+    DSPX_ERR_HOST = -6       /* a host-side failure inside the library (e.g. a staging thread could not start) */
 } dspx_status;
 
 /* Arithmetic mode of the filter kernels (the `flags` argument). */

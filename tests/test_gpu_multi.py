@@ -1,0 +1,157 @@
+"""The multi-device host sharder (dspx_fir_f64_multi, dspx_lfilter_f64_multi, dspx_cwt_f64_multi) with more than
+one logical device: a thread, a staging engine and a plan per device, all running at once.  On a one-GPU machine
+DSPX_ALIAS_DEVICES=1 maps the logical devices onto the GPU that is there (the code path is the same, only
+hipSetDevice's argument differs); the same checks run un-aliased when the machine has two GPUs or more.
+Results must be the same bits for every device count, and must meet the parity bar against the oracle."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import scaled_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-12
+COUNTS = (2, 3, 8)
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+@pytest.fixture(scope="module")
+def dsp():
+    import torch
+
+    import dsp_amd
+
+    assert torch.cuda.is_available() and dsp_amd.device_count() >= 1
+    return dsp_amd
+
+
+@pytest.fixture(params=["aliased", "physical"])
+def counts(request, dsp):
+    """Device counts to run with; sets / clears the aliasing knob around the test."""
+    old = os.environ.pop("DSPX_ALIAS_DEVICES", None)
+    if request.param == "aliased":
+        os.environ["DSPX_ALIAS_DEVICES"] = "1"
+        yield COUNTS
+    else:
+        have = dsp.device_count()
+        if have < 2:
+            pytest.skip("needs two GPUs or more")
+        yield tuple(g for g in COUNTS if g <= have)
+    os.environ.pop("DSPX_ALIAS_DEVICES", None)
+    if old is not None:
+        os.environ["DSPX_ALIAS_DEVICES"] = old
+
+
+def lfilter_multi(dsp, b, x, ngpus, exact=False, mfma=None):
+    from dsp_amd.api import _flags, _np_f64
+    from dsp_amd._lib import check, lib
+
+    b, x = _np_f64(b), _np_f64(x)
+    x2 = x.reshape(1, -1) if x.ndim == 1 else x
+    y = np.full_like(x2, np.nan)
+    check(lib().dspx_fir_f64_multi(b.ctypes.data, b.size, x2.ctypes.data, y.ctypes.data, x2.shape[0], x2.shape[1],
+                                   x2.shape[1], int(ngpus), _flags(exact, mfma)))
+    return y.reshape(x.shape)
+
+
+@pytest.mark.parametrize("ntaps", [31, 255])
+def test_fir_channel_ranges(dsp, oracle, counts, ntaps):
+    """nchan >= G: contiguous channel ranges per device."""
+    taps = dsp.firwin(ntaps, 0.25)
+    nchan, n = 21, 200_003
+    x = np.stack([oracle.fill_splitmix(n, dsp.SEED, c * n) for c in range(nchan)])
+    ref = np.stack([oracle.lfilter(taps, [1.0], x[c]) for c in range(nchan)])
+    one = lfilter_multi(dsp, taps, x, 1)
+    assert scaled_err(one, ref) <= TOL
+    for g in counts:
+        assert np.array_equal(bits(lfilter_multi(dsp, taps, x, g)), bits(one)), g
+        assert np.array_equal(bits(lfilter_multi(dsp, taps, x, g, exact=True)), bits(ref)), g
+
+
+@pytest.mark.parametrize("ntaps,nchan,n", [(101, 1, 3_000_001), (255, 2, 1_500_007), (4095, 1, 700_001)])
+def test_fir_segments_with_history(dsp, oracle, counts, ntaps, nchan, n):
+    """nchan < G: every device filters a segment of every channel, with the ntaps-1 samples before it as history."""
+    taps = dsp.firwin(ntaps, 0.2)
+    x = np.stack([oracle.fill_splitmix(n, dsp.SEED, c * n) for c in range(nchan)])
+    one = lfilter_multi(dsp, taps, x, 1)
+    ref = np.stack([oracle.lfilter(taps, [1.0], x[c]) for c in range(nchan)])
+    assert scaled_err(one, ref) <= TOL
+    for g in counts:
+        if g <= nchan:
+            continue
+        assert np.array_equal(bits(lfilter_multi(dsp, taps, x, g)), bits(one)), g
+        assert np.array_equal(bits(lfilter_multi(dsp, taps, x, g, exact=True)), bits(ref)), g
+
+
+def test_recursive_filter_shards_whole_channels(dsp, oracle, counts):
+    """A recursive filter's state is serial along a channel: with fewer channels than devices only nchan devices
+    work, each on whole channels whose state travels from staged piece to staged piece."""
+    from scipy import signal
+
+    for (b, a), nchan, n in ((signal.butter(4, 0.2), 3, 150_000), (signal.butter(2, 0.1), 11, 70_001),
+                             (signal.butter(6, 0.3), 2, 400_003)):
+        x = np.stack([oracle.fill_splitmix(n, dsp.SEED, c << 24) for c in range(nchan)])
+        ref = np.stack([oracle.lfilter(b, a, x[c]) for c in range(nchan)])
+        one = dsp.lfilter_iir(b, a, x, ngpus=1)
+        assert scaled_err(one, ref) <= TOL
+        for g in counts:
+            assert np.array_equal(bits(dsp.lfilter_iir(b, a, x, ngpus=g)), bits(one)), (g, nchan)
+            assert np.array_equal(bits(dsp.lfilter_iir(b, a, x, ngpus=g, exact=True)), bits(ref)), (g, nchan)
+
+
+def test_wavelet_bank_shards_scales(dsp, oracle, counts):
+    psi, wx = dsp.integrate_wavelet(10)
+    scales = np.arange(1, 31, dtype=np.float64)
+    sig = oracle.fill_splitmix(20_011, dsp.SEED, 3)
+    ref = oracle.cwt(sig, scales, psi, wx)
+    one = dsp.cwt(sig, scales, psi, wx, ngpus=1)
+    for r in range(scales.size):
+        assert scaled_err(one[r], ref[r]) <= 1e-11, r   # the transform differences two large sums (see test_cwt.py)
+    for g in counts:
+        assert np.array_equal(bits(dsp.cwt(sig, scales, psi, wx, ngpus=g)), bits(one)), g
+
+
+def test_device_count_beyond_the_machine_is_refused(dsp):
+    os.environ.pop("DSPX_ALIAS_DEVICES", None)
+    with pytest.raises(dsp.DspxError, match="exceeds visible devices"):
+        lfilter_multi(dsp, np.ones(3), np.ones(100), dsp.device_count() + 1)
+
+
+def test_recursive_channels_of_several_pieces_do_not_mix_states(dsp, oracle):
+    """Several channels that each span several staged pieces, on one device: a piece starts from the final state
+    of the piece before it in ITS channel (each staging slot keeps its own piece's state), whatever the streams'
+    relative timing.  Exact mode is bit-identical to the reference loop, the default mode within tolerance."""
+    from scipy import signal
+
+    for (b, a), nchan, n in ((signal.butter(4, 0.2), 3, 150_000), (signal.butter(2, 0.1), 4, 140_001),
+                             (signal.butter(3, 0.15), 12, 70_000)):
+        x = np.stack([oracle.fill_splitmix(n, dsp.SEED, c << 24) for c in range(nchan)])
+        ref = np.stack([oracle.lfilter(b, a, x[c]) for c in range(nchan)])
+        for _ in range(3):
+            assert np.array_equal(bits(dsp.lfilter_iir(b, a, x, exact=True)), bits(ref))
+            assert scaled_err(dsp.lfilter_iir(b, a, x), ref) <= TOL
+
+
+@pytest.mark.parametrize("order,wn", [(2, 0.2), (6, 0.3)])
+def test_tile_scan_in_several_passes(dsp, oracle, order, wn):
+    """More than 4096 tiles in one channel of one device call (n > 2^24): the tile-state scan runs in passes that
+    carry the state from one pass to the next.  With and without incoming output history."""
+    import torch
+    from scipy import signal
+
+    b, a = signal.butter(order, wn)
+    n = (1 << 24) + 3 * 4096 + 5
+    xh = oracle.fill_splitmix(n, dsp.SEED, 77)
+    ref = oracle.lfilter(b, a, xh)
+    x = torch.from_numpy(xh).cuda()
+    bt = torch.from_numpy(b).cuda()
+    y = dsp.lfilter_iir_device(bt, a, x)
+    assert scaled_err(y.cpu().numpy(), ref) <= TOL
+    cut = 4099
+    second = dsp.lfilter_iir_device(bt, a, x[cut:].contiguous(), xhist=x[cut - (b.size - 1):cut].contiguous(),
+                                    yhist=y[cut - (a.size - 1):cut].contiguous())
+    assert scaled_err(second.cpu().numpy(), ref[cut:]) <= TOL
