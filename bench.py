@@ -6,9 +6,12 @@
 A step is one pass of the device-resident filter (dspx_fir_f64_dev) over one batch of
 synthetic input that already sits in HBM.  The default workload is the configuration the
 headline metric is quoted on: 4096 channels x 2^20 samples, 255-tap firwin(255, 0.25).
-With N > 1 (launched by torch.distributed.run, one rank per GPU) every rank filters its own
-batch of that size (weak scaling; channels are independent, so there is no data-path
-collective); `--scaling strong` shards the 4096 channels over the ranks instead.
+With N > 1 there is one process (rank) per GPU: either started by torch.distributed.run, or, when
+no launcher set WORLD_SIZE, by this script itself, which then only spawns the N ranks, forwards rank
+0's JSON line and returns the worst exit code (it never touches a GPU).  Every rank filters its own
+batch of that size (weak scaling; channels are independent, so there is no data-path collective);
+`--scaling strong` shards the 4096 channels over the ranks instead.  After the timed region the ranks
+all-gather a small slice of their results over RCCL (reported apart as `allgather`, never part of `value`).
 
 Rank 0 prints ONE JSON line with the metric, the roofline of the FIR kernel (per-launch HIP
 events on the launch stream) and, at N = 1, the CPU baseline (the reference's own single-threaded
@@ -18,8 +21,11 @@ sample of the same workload).
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -55,7 +61,9 @@ def parse_args():
     ap.add_argument("--exact", action="store_true", help="DSPX_FIR_EXACT arithmetic (separate mul/add)")
     ap.add_argument("--vector", action="store_true", help="force the vector-pipe kernel (DSPX_FIR_VECTOR)")
     ap.add_argument("--allgather", action="store_true",
-                    help="with --scaling strong and N > 1: also time an all-gather of the result shards (reported apart)")
+                    help="with --scaling strong and N > 1: also time an all-gather of the WHOLE result (reported apart); "
+                         "without it a 64-channel slice per rank is gathered")
+    ap.add_argument("--no-allgather", action="store_true", help="skip the all-gather sub-record")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-samples", type=int, default=1 << 27, help="samples of the workload the CPU baseline filters")
     return ap.parse_args()
@@ -124,7 +132,7 @@ def cpu_baseline(taps: np.ndarray, n: int, nsamples: int, y_gpu) -> dict:
     return res
 
 
-def run_cwt(args, rank, world, dev, dist, red_dev):
+def run_cwt(args, rank, world, dev, dist, red_dev, ranks_seen=1):
     """The wavelet-bank workload: every rank transforms its own 2^22-sample signal (weak scaling)."""
     import torch
 
@@ -162,24 +170,25 @@ def run_cwt(args, rank, world, dev, dist, red_dev):
     if rank != 0:
         return
     dt_max, kern_ms = float(t[0]), float(t[1])
+    traffic, traffic_src = load_traffic("cwt65")
     flops = 2.0 * bank.total_taps * n            # 2 * 34385 per input sample
     bytes_alg = (8.0 + 8.0 * nscales) * n        # read once, one output row per scale
     sec = kern_ms / 1e3
     res = {
         "metric": "dsp::cwt input GS/s (65-scale Morlet bank)", "value": world * n * args.steps / dt_max / 1e9,
-        "unit": "GS/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "unit": "GS/s", "n_gpus": world, "ranks_seen": ranks_seen, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt_max / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic (splitmix64 uniform [-1,1), generated on device, resident in HBM)",
         "config": {"workload": CWT["desc"], "samples": n, "scales": nscales, "total_taps": bank.total_taps,
                    "arithmetic": "exact (mul+add)" if args.exact else "fma"},
         "roofline": {"bound": "mfma", "achieved": flops / sec / 1e12, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
-                     "frac": flops / sec / 1e12 / PEAK_FP64_TFLOPS, "traffic": load_traffic("cwt65"),
+                     "frac": flops / sec / 1e12 / PEAK_FP64_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                      "kernel": "fir_f64_kernel (bank mode, vector pipe)" if args.vector or args.exact else
                                "fir_f64_mfma_kernel + fir_f64_kernel (bank mode; rows of >= 96 taps on the matrix pipe)",
                      "kernel_ms": kern_ms,
                      "note": "FP64 FMA; algorithmic flops = 2 * sum of per-scale tap counts per input sample"},
         "roofline_other": {"bound": "hbm", "achieved": bytes_alg / sec / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                           "frac": bytes_alg / sec / 1e9 / PEAK_HBM_GBS, "traffic": load_traffic("cwt65")},
+                           "frac": bytes_alg / sec / 1e9 / PEAK_HBM_GBS, "traffic": traffic, "traffic_source": traffic_src},
     }
     if world == 1 and not args.no_cpu_baseline:
         from oracle.pyoracle import SEED, Oracle, Reference, reference_available
@@ -215,7 +224,7 @@ def butter2(wn: float):
     return np.array([b0, 2.0 * b0, b0]), np.array([1.0, 2.0 * (k * k - 1.0) * norm, (1.0 - np.sqrt(2.0) * k + k * k) * norm])
 
 
-def run_iir(args, rank, world, dev, dist, red_dev):
+def run_iir(args, rank, world, dev, dist, red_dev, ranks_seen=1):
     """lfilter with a recursive part (reference dsp.hpp:366-368): 4096 channels x 2^20 samples through a biquad,
     every rank its own batch (weak scaling)."""
     import torch
@@ -258,16 +267,17 @@ def run_iir(args, rank, world, dev, dist, red_dev):
     dt_max, kern_ms = float(t[0]), float(t[1])
     sec = kern_ms / 1e3
     bytes_alg = 16.0 * nchan * n
+    traffic, traffic_src = load_traffic("iir_biquad")
     res = {
         "metric": "FP64 lfilter output GS/s (3-tap numerator, 2 poles)", "value": world * nchan * n * args.steps / dt_max / 1e9,
-        "unit": "GS/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "unit": "GS/s", "n_gpus": world, "ranks_seen": ranks_seen, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt_max / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic (splitmix64 uniform [-1,1), generated on device, resident in HBM)",
         "config": {"workload": "lfilter(b, a, x) with a recursive part: 4096 x 2^20 samples, Butterworth biquad (cutoff 0.2)",
                    "nchan_per_gpu": nchan, "samples_per_channel": n, "nb": 3, "na": 3,
                    "arithmetic": "exact (sequential, mul+sub)" if args.exact else "fma, block-parallel"},
         "roofline": {"bound": "hbm", "achieved": bytes_alg / sec / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                     "frac": bytes_alg / sec / 1e9 / PEAK_HBM_GBS, "traffic": load_traffic("iir_biquad"),
+                     "frac": bytes_alg / sec / 1e9 / PEAK_HBM_GBS, "traffic": traffic, "traffic_source": traffic_src,
                      "kernel": "iir_seq_kernel after fir_f64_kernel" if args.exact else
                                "iir_walk_kernel (one workgroup per channel, FIR part computed in the same pass)",
                      "kernel_ms": kern_ms,
@@ -297,26 +307,145 @@ def run_iir(args, rank, world, dev, dist, red_dev):
     print(json.dumps(res), flush=True)
 
 
+def kernel_source_hash(workload: str) -> str:
+    """SHA-256 of the source file that holds the workload's dominant kernel."""
+    name = "iir_kernels.hip" if workload == "iir_biquad" else "fir_kernels.hip"
+    with open(os.path.join(ROOT, "dsp_amd", "csrc", name), "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()
+
+
 def load_traffic(workload: str):
-    """HBM bytes per launch from the committed PMC summary, if one exists for this workload."""
+    """(HBM bytes per launch, where the figure comes from).  The bytes are PMC counters (FETCH_SIZE, WRITE_SIZE)
+    of a profiled run of this same command, kept in profiles/pmc_traffic.json -- they are not measured in this
+    run.  The entry records the hash of the kernel source it was profiled with; when the source has changed
+    since, the figure is stale and None is reported instead."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(path) as f:
-            return json.load(f).get(workload, {}).get("hbm_bytes_per_launch")
+            entry = json.load(f).get(workload)
     except (OSError, ValueError):
-        return None
+        entry = None
+    if not entry:
+        return None, "no PMC profile of this workload under profiles/"
+    want = entry.get("kernel_source_sha256")
+    if want != kernel_source_hash(workload):
+        return None, f"stale: {entry.get('source')} was taken with another version of the kernel source"
+    return entry.get("hbm_bytes_per_launch"), f"{entry.get('source')}; profiled run, kernel source sha256 {want[:12]}"
+
+
+def launch_ranks(args) -> int:
+    """--gpus N > 1 without a launcher: start N fresh processes of this script, one per GPU, with the
+    torch.distributed environment set (RANK, LOCAL_RANK, WORLD_SIZE, MASTER_ADDR, MASTER_PORT).  This process
+    has not touched a GPU (no torch import, no HIP call) and never does; rank 0 prints the JSON line straight to
+    the inherited stdout.  Returns the worst exit code; when a rank fails, the others are ended after a short grace
+    period (they would wait for it in a barrier for ever)."""
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env))
+    worst, failed_at = 0, None
+    limit = time.monotonic() + float(os.environ.get("DSPX_BENCH_TIMEOUT", "1500"))
+    live = list(procs)
+    while live:
+        time.sleep(0.2)
+        for p in list(live):
+            rc = p.poll()
+            if rc is None:
+                continue
+            live.remove(p)
+            if rc != 0:
+                worst = rc if worst == 0 else worst
+                failed_at = failed_at or time.monotonic()
+        overdue = time.monotonic() > limit
+        if live and (overdue or (failed_at and time.monotonic() - failed_at > float(os.environ.get("DSPX_BENCH_FAIL_GRACE", "20")))):
+            for p in live:          # exactly the processes started above
+                p.terminate()
+            for p in live:
+                try:
+                    p.wait(timeout=10)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+                    p.wait()
+            worst = worst or 124
+            live = []
+    if worst:
+        print(f"bench.py: a rank failed (exit code {worst})", file=sys.stderr, flush=True)
+    return worst if 0 < worst < 256 else (1 if worst else 0)
+
+
+def dry_run(args, rank: int, world: int) -> None:
+    """DSPX_BENCH_DRY=1: the ranks only meet (gloo, no GPU, no filter) and rank 0 prints who took part.  What the
+    CPU tests use to check the launcher: environment, rendezvous, forwarding of the line and of exit codes.
+    DSPX_BENCH_DRY=fail<r> makes rank r exit with code 3 before the rendezvous."""
+    mode = os.environ["DSPX_BENCH_DRY"]
+    if mode == f"fail{rank}":
+        raise SystemExit(3)
+    seen = 1
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+
+        dist.init_process_group(backend="gloo")
+        one = torch.ones(1, dtype=torch.int64)
+        dist.all_reduce(one)
+        seen = int(one[0])
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "ranks_seen": seen, "steps": args.steps,
+                          "warmup": args.warmup, "workload": args.workload}), flush=True)
+
+
+def small_allgather(dsp_amd, dist, torch, y, rank, world, fence, on_gpu: bool):
+    """The optional exchange step of the path on a bounded slice: every rank contributes its first `rows` result
+    channels and receives those of all ranks (all_gather_into_tensor over the process group: RCCL over xGMI when
+    on_gpu, else the rehearsal backend on host copies).  Checked against per-rank checksums gathered beside it.
+    Returns the sub-record (identical on every rank)."""
+    rows = min(64, y.shape[0])
+    n = y.shape[1]
+    mine_dev = y[:rows].contiguous()
+    try:
+        own = dsp_amd.checksum(mine_dev, 0)
+        mine = mine_dev if on_gpu else mine_dev.cpu()
+        sums = torch.zeros(world, dtype=torch.int64, device=mine.device)
+        sums[rank] = own - (1 << 64) if own >= (1 << 63) else own
+        dist.all_reduce(sums)                                   # sum of one-hot vectors = every rank's checksum
+        full = dsp_amd.allgather_channels(mine, rows * world)   # warm-up: sets up the communicator's channels
+        fence()
+        t0 = time.perf_counter()
+        full = dsp_amd.allgather_channels(mine, rows * world)
+        fence()
+        ms = (time.perf_counter() - t0) * 1e3
+        full = full.to(y.device)
+        ok = all((dsp_amd.checksum(full[r * rows:(r + 1) * rows].contiguous(), 0) - int(sums[r])) % (1 << 64) == 0
+                 for r in range(world))
+        t = torch.tensor([ms, 0.0 if ok else 1.0], dtype=torch.float64, device=mine.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        recv = 8.0 * rows * n * (world - 1)
+        return {"ms": float(t[0]), "rows_per_rank": rows, "bytes_received_per_gpu": recv,
+                "GB/s_per_gpu": recv / float(t[0]) / 1e6, "matches_per_rank_checksums": float(t[1]) == 0.0,
+                "transport": "RCCL (nccl backend), device buffers" if on_gpu else "rehearsal backend, host copies",
+                "note": "all_gather_into_tensor of a slice of the result shards over the process group, outside the "
+                        "timed region; not part of value"}
+    except Exception as e:  # noqa: BLE001 -- the optional exchange must never take the metric down with it
+        return {"error": f"{type(e).__name__}: {e}"}
 
 
 def main() -> None:
     args = parse_args()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args))   # this process only spawns the ranks; it never touches a GPU
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with: python -m torch.distributed.run --nnodes=1 "
-                             "--nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
         raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
+    if os.environ.get("DSPX_BENCH_DRY"):
+        return dry_run(args, rank, world)
 
     import torch
     import torch.distributed as dist
@@ -339,9 +468,15 @@ def main() -> None:
             dist.init_process_group(backend="nccl", device_id=dev)
         else:
             dist.init_process_group(backend=backend)
+    # how many ranks really take part: a sum over the process group (RCCL on GPUs), not the environment
+    ranks_seen = 1
+    if world > 1:
+        one = torch.ones(1, dtype=torch.int64, device=red_dev)
+        dist.all_reduce(one)
+        ranks_seen = int(one[0])
 
     if args.workload in ("cwt65", "iir_biquad"):
-        (run_cwt if args.workload == "cwt65" else run_iir)(args, rank, world, dev, dist, red_dev)
+        (run_cwt if args.workload == "cwt65" else run_iir)(args, rank, world, dev, dist, red_dev, ranks_seen)
         if world > 1:
             dist.barrier()
             dist.destroy_process_group()
@@ -401,6 +536,9 @@ def main() -> None:
 
     # optional exchange step, timed apart from the filter: every rank receives all result shards over RCCL
     gather_ms = 0.0
+    gather_small = None
+    if world > 1 and not args.no_allgather and not (args.allgather and args.scaling == "strong"):
+        gather_small = small_allgather(dsp_amd, dist, torch, y, rank, world, fence, backend == "nccl")
     if args.allgather and world > 1 and args.scaling == "strong" and backend == "nccl":
         nchan_total = WORKLOADS[args.workload][0]
         full = dsp_amd.allgather_channels(y, nchan_total)   # warm-up (also sets up the communicator's buffers)
@@ -421,18 +559,19 @@ def main() -> None:
         matrix = not args.exact and not args.vector and numtaps >= dsp_amd.MATRIX_PIPE_MIN_TAPS
         kernel_name = "fir_f64_mfma_kernel (v_mfma_f64_16x16x4_f64)" if matrix else "fir_f64_kernel (v_fma_f64)"
         outputs_per_launch = nchan * n_local
-        traffic = load_traffic(args.workload) if (n_local == n and nchan == WORKLOADS[args.workload][0]) else None
+        traffic, traffic_src = (load_traffic(args.workload) if (n_local == n and nchan == WORKLOADS[args.workload][0])
+                                else (None, "this rank's shard is not the profiled launch"))
         flops = 2.0 * numtaps * outputs_per_launch
         bytes_alg = 16.0 * outputs_per_launch
         sec = kern_ms_max / 1e3
         fp64 = {"bound": "mfma", "achieved": flops / sec / 1e12, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
-                "frac": flops / sec / 1e12 / PEAK_FP64_TFLOPS, "traffic": traffic,
+                "frac": flops / sec / 1e12 / PEAK_FP64_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                 "kernel": kernel_name, "kernel_ms": kern_ms_max,
                 "note": "MI355X FP64 peak: matrix pipe = vector pipe = 78.6 TFLOP/s, so one number bounds both kernels. "
                         "algorithmic flops = 2*ntaps per output (the Toeplitz-block kernel's multiplies by zero taps "
                         "are not counted)"}
         hbm = {"bound": "hbm", "achieved": bytes_alg / sec / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-               "frac": bytes_alg / sec / 1e9 / PEAK_HBM_GBS, "traffic": traffic,
+               "frac": bytes_alg / sec / 1e9 / PEAK_HBM_GBS, "traffic": traffic, "traffic_source": traffic_src,
                "kernel": kernel_name, "kernel_ms": kern_ms_max,
                "note": "algorithmic bytes = 16 per output (8 read + 8 written)"}
         # the binding roof is the one that allows fewer samples per second
@@ -444,6 +583,7 @@ def main() -> None:
             "value": units_per_step_all * args.steps / dt_max / 1e9,
             "unit": "GS/s",
             "n_gpus": world,
+            "ranks_seen": ranks_seen,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": dt_max / args.steps * 1e3,
@@ -459,6 +599,8 @@ def main() -> None:
             "roofline": primary,
             "roofline_other": secondary,
         }
+        if gather_small is not None:
+            out["allgather"] = gather_small
         if gather_ms > 0.0:
             total_bytes = 8.0 * WORKLOADS[args.workload][0] * n
             out["allgather"] = {"ms": gather_ms, "bytes_received_per_gpu": total_bytes * (world - 1) / world,

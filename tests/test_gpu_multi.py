@@ -155,3 +155,31 @@ def test_tile_scan_in_several_passes(dsp, oracle, order, wn):
     second = dsp.lfilter_iir_device(bt, a, x[cut:].contiguous(), xhist=x[cut - (b.size - 1):cut].contiguous(),
                                     yhist=y[cut - (a.size - 1):cut].contiguous())
     assert scaled_err(second.cpu().numpy(), ref[cut:]) <= TOL
+
+
+def test_bench_two_ranks_without_a_launcher():
+    """`python bench.py --gpus 2` started plainly: the script spawns its ranks itself.  Both ranks share the one GPU
+    of the test machine and meet over gloo (RCCL refuses two ranks on one device); on a machine with two GPUs the
+    same command runs with RCCL and one GPU per rank."""
+    import json
+    import subprocess
+    import sys
+
+    import torch
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "DSPX_ALIAS_DEVICES"):
+        env.pop(k, None)
+    if torch.cuda.device_count() < 2:
+        env.update(DSPX_BENCH_BACKEND="gloo", DSPX_BENCH_ONE_DEVICE="1")
+    for scaling in ("weak", "strong"):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "small255",
+                            "--steps", "3", "--warmup", "1", "--scaling", scaling], env=env, capture_output=True,
+                           text=True, timeout=280)
+        assert r.returncode == 0, r.stderr[-3000:]
+        lines = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1
+        out = lines[0]
+        assert out["n_gpus"] == 2 and out["ranks_seen"] == 2 and out["scaling"] == scaling and out["value"] > 0
+        assert out["allgather"].get("matches_per_rank_checksums") is True, out["allgather"]

@@ -94,3 +94,48 @@ def test_world_size_2_gloo(dsp):
     assert rep["weak"] == [[4096, 0, 2 * (4096 << 20)], [4096, 4096, 2 * (4096 << 20)]]
     assert rep["max_over_ranks"] == 2.0
     assert rep["allgather_6"] and rep["allgather_5"]
+
+
+def run_bench(extra_env, *argv, timeout=300):
+    import json
+    import subprocess
+    import sys
+
+    env = dict(os.environ, **extra_env)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], env=env, capture_output=True, text=True,
+                       timeout=timeout)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    return r, [json.loads(ln) for ln in lines]
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus N` with no launcher around it: the parent spawns N ranks (before touching any GPU),
+    exactly one JSON line comes back, and ranks_seen is counted by a reduction over the process group."""
+    r, lines = run_bench({"DSPX_BENCH_DRY": "1"}, "--gpus", "2", "--workload", "small255", "--steps", "3")
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 2 and lines[0]["ranks_seen"] == 2 and lines[0]["steps"] == 3
+    r, lines = run_bench({"DSPX_BENCH_DRY": "1"}, "--gpus", "4")
+    assert r.returncode == 0 and lines[0]["ranks_seen"] == 4
+    # one process when N = 1: no spawning, the line is the process's own
+    r, lines = run_bench({"DSPX_BENCH_DRY": "1"}, "--gpus", "1")
+    assert r.returncode == 0 and lines[0]["n_gpus"] == 1 and lines[0]["ranks_seen"] == 1
+
+
+def test_bench_forwards_a_failing_rank():
+    """A rank that dies takes the run down with a non-zero exit code instead of leaving the others in a barrier."""
+    r, lines = run_bench({"DSPX_BENCH_DRY": "fail1", "DSPX_BENCH_FAIL_GRACE": "2"}, "--gpus", "2", timeout=120)
+    assert r.returncode != 0 and not lines
+    assert "a rank failed" in r.stderr
+
+
+def test_bench_parent_does_not_import_torch_before_spawning():
+    """The spawning parent must never initialise a GPU: importing bench and parsing arguments pulls in neither torch
+    nor the HIP library."""
+    import subprocess
+    import sys
+
+    code = ("import sys; sys.argv=['bench.py','--gpus','2']; import bench; bench.parse_args(); "
+            "assert 'torch' not in sys.modules and 'dsp_amd' not in sys.modules, sorted(sys.modules)")
+    subprocess.run([sys.executable, "-c", code], cwd=ROOT, check=True, timeout=60)

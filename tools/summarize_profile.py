@@ -53,8 +53,12 @@ out["derived"] = {
 json.dump(out, open(os.path.join(prof, f"{tag}_pmc_summary.json"), "w"), indent=1)
 tpath = os.path.join(prof, "pmc_traffic.json")
 tr = json.load(open(tpath)) if os.path.exists(tpath) else {}
+# the figure belongs to the kernel source it was profiled with: bench.py reports it only while that source is unchanged
+import hashlib
+ksrc = os.path.join(root, "dsp_amd", "csrc", "iir_kernels.hip" if workload == "iir_biquad" else "fir_kernels.hip")
 tr[workload] = {"hbm_bytes_per_launch": out["derived"]["hbm_read_bytes_per_launch"] + out["derived"]["hbm_write_bytes_per_launch"],
-                "source": f"profiles/{tag}_pmc_summary.json (FETCH_SIZE x2 + WRITE_SIZE, KB -> bytes)"}
+                "source": f"profiles/{tag}_pmc_summary.json (FETCH_SIZE x2 + WRITE_SIZE, KB -> bytes)",
+                "kernel_source_sha256": hashlib.sha256(open(ksrc, "rb").read()).hexdigest()}
 json.dump(tr, open(tpath, "w"), indent=1)
 print(open(os.path.join(prof, f"{tag}_kernel_stats.csv")).read()[:700])
 print(json.dumps(out["derived"], indent=1))
