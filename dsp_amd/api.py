@@ -14,10 +14,9 @@ from . import _lib
 from ._lib import DSPX_FIR_EXACT, DSPX_FIR_FMA, DSPX_FIR_MFMA, DSPX_FIR_VECTOR, check, lib
 
 SEED = 0x44535046495236
-# Pipe selection of the default flags (mirrors kMatrixPipeMinTaps / kMatrixPipeWideTaps in csrc/dspx_common.h):
-# filters of at least MATRIX_PIPE_MIN_TAPS taps run on the FP64 matrix pipe, from MATRIX_PIPE_WIDE_TAPS on 4096-output tiles.
-MATRIX_PIPE_MIN_TAPS = 96
-MATRIX_PIPE_WIDE_TAPS = 224
+# Pipe selection of the default flags (mirrors kMatrixPipeMinTaps in csrc/dspx_common.h):
+# filters of at least MATRIX_PIPE_MIN_TAPS taps run on the FP64 matrix pipe.
+MATRIX_PIPE_MIN_TAPS = 56
 
 
 def device_count() -> int:

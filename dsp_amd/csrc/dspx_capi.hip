@@ -55,8 +55,7 @@ int launch_dev(const double* d_taps, size_t ntaps, const double* d_x, size_t x_s
                size_t hist_stride, double* d_y, size_t y_stride, size_t nchan, size_t n, unsigned flags,
                hipStream_t stream) {
     const bool mfma = dspx::use_matrix_pipe(flags, ntaps);
-    const int ob = dspx::matrix_row_blocks(ntaps);
-    const size_t tile = (size_t)(mfma ? dspx::fir_mfma_tile(ob) : dspx::fir_tile());
+    const size_t tile = (size_t)(mfma ? dspx::fir_mfma_tile() : dspx::fir_tile());
     const size_t tiles_per_chan = (n + tile - 1) / tile;
     if (tiles_per_chan > 0xffffffffull) return fail(DSPX_ERR_INVALID, "n too large for one launch: %zu", n);
     const bool vec2 = aligned16(d_x) && aligned16(d_y) && (x_stride % 2 == 0) && (y_stride % 2 == 0);
@@ -76,7 +75,7 @@ int launch_dev(const double* d_taps, size_t ntaps, const double* d_x, size_t x_s
         if (mfma)
             DSPX_HIP(dspx::launch_fir_mfma_f64(d_taps, d_x + c0 * x_stride,
                                                d_hist ? d_hist + c0 * hist_stride : nullptr, d_y + c0 * y_stride, s,
-                                               ob, vec2, stream));
+                                               vec2, stream));
         else
             DSPX_HIP(dspx::launch_fir_f64(d_taps, d_x + c0 * x_stride, d_hist ? d_hist + c0 * hist_stride : nullptr,
                                           d_y + c0 * y_stride, s, (flags & DSPX_FIR_EXACT) != 0, vec2, stream));

@@ -25,7 +25,7 @@ int fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
 constexpr unsigned long long kMaxGrid = (1ull << 24) - 1;
 
 // Taps from which the FP64 matrix pipe is faster than the vector pipe (measured on MI355X).
-constexpr size_t kMatrixPipeMinTaps = 96;
+constexpr size_t kMatrixPipeMinTaps = 56;
 
 inline int check_flags(unsigned flags) {
     if (flags & ~(DSPX_FIR_EXACT | DSPX_FIR_MFMA | DSPX_FIR_VECTOR))
@@ -41,11 +41,6 @@ inline bool use_matrix_pipe(unsigned flags, size_t ntaps) {
     if (flags & DSPX_FIR_MFMA) return true;
     return ntaps >= kMatrixPipeMinTaps;
 }
-
-// Row blocks (of 16 outputs) per segment of the matrix-pipe kernel: the 2048-output tile keeps more
-// workgroups resident and wins below kMatrixPipeWideTaps; above, the 4096-output tile reads less LDS per product.
-constexpr size_t kMatrixPipeWideTaps = 224;
-inline int matrix_row_blocks(size_t ntaps) { return ntaps >= kMatrixPipeWideTaps ? 4 : 2; }
 
 // Copies `rows` rows of `n` doubles from device memory (row r at d_src + r*src_pitch) into host memory (row r
 // to dst + (row_map ? row_map[r] : r)*dst_stride) through the pinned staging pipeline of the host-pointer

@@ -160,24 +160,21 @@ int apply_bank(const dspx_cwt_bank* bank, const double* d_signal, size_t n, doub
     if (!d_signal || !d_result) return fail(DSPX_ERR_INVALID, "NULL pointer");
     if (row_stride < n) return fail(DSPX_ERR_INVALID, "row_stride (%zu) < n (%zu)", row_stride, n);
     const bool vec2 = dspx::aligned16(d_signal) && dspx::aligned16(d_result) && (row_stride % 2 == 0);
-    // Each row runs on the pipe and tile its own tap count selects, whatever other rows the bank holds, so
-    // that a row's bits do not depend on how scales are sharded.  Rows are stored longest first: wide-tile
-    // matrix rows, then narrow-tile matrix rows, then vector rows are consecutive runs of the descriptors.
+    // Each row runs on the pipe its own tap count selects, whatever other rows the bank holds, so that a row's bits
+    // do not depend on how scales are sharded.  Rows are stored longest first: matrix-pipe rows, then vector-pipe
+    // rows are consecutive runs of the descriptors.
     size_t first = 0;
-    for (int part = 0; part < 3 && first < bank->nrows; ++part) {
-        const bool mfma = part < 2;
-        const int ob = part == 0 ? 4 : 2;
+    for (int part = 0; part < 2 && first < bank->nrows; ++part) {
+        const bool mfma = part == 0;
         size_t end = first;
         if (mfma) {
-            while (end < bank->nrows && dspx::use_matrix_pipe(flags, (size_t)bank->row_taps[end]) &&
-                   dspx::matrix_row_blocks((size_t)bank->row_taps[end]) == ob)
-                ++end;
+            while (end < bank->nrows && dspx::use_matrix_pipe(flags, (size_t)bank->row_taps[end])) ++end;
         } else {
             end = bank->nrows;
         }
         const size_t count = end - first;
         if (count == 0) continue;
-        const size_t stride = (size_t)(mfma ? dspx::fir_mfma_bank_stride(ob) : dspx::fir_bank_stride());
+        const size_t stride = (size_t)(mfma ? dspx::fir_mfma_bank_stride() : dspx::fir_bank_stride());
         const size_t tiles_per_row = (n + stride - 1) / stride;
         const size_t run = (tiles_per_row + 7) / 8;  // tiles per row and XCD
         const size_t max_rows = dspx::kMaxGrid / (8 * run);
@@ -188,11 +185,13 @@ int apply_bank(const dspx_cwt_bank* bank, const double* d_signal, size_t n, doub
             s.y_stride = row_stride;
             s.n = (long long)n;
             s.tiles_per_chan = (unsigned)tiles_per_row;
-            s.total_tiles = (unsigned)(nr * 8 * run);  // workgroups; those past a row's last tile exit at once
+            // positions of the rows' tiles: every row is cut into 8 runs of `run` tiles, one per XCD (vector kernel: one
+            // workgroup per position, those past a row's last tile exit at once; matrix kernel: walked by its workgroups)
+            s.total_tiles = (unsigned)(nr * 8 * run);
             dspx::set_divider(s, (unsigned)run);
             if (mfma)
                 DSPX_HIP(dspx::launch_fir_mfma_bank_f64(bank->d_taps, bank->d_rows + first + r0, d_signal, d_result,
-                                                        s, ob, vec2, stream));
+                                                        s, vec2, stream));
             else
                 DSPX_HIP(dspx::launch_fir_bank_f64(bank->d_taps, bank->d_rows + first + r0, d_signal, d_result, s,
                                                    (flags & DSPX_FIR_EXACT) != 0, vec2, stream));

@@ -11,7 +11,8 @@ struct FirShape {
     long long n;                     // samples per channel
     unsigned long long div_magic;    // tile_id / tiles_per_chan == (tile_id * div_magic) >> div_shift
     unsigned div_shift;
-    unsigned total_tiles;            // nchan * tiles_per_chan  (< 2^24: grid * 256 threads must stay below 2^32)
+    unsigned total_tiles;            // nchan * tiles_per_chan  (vector kernel: the grid, < 2^24 as grid * 256 threads must
+                                     // stay below 2^32; matrix kernel: what its persistent workgroups walk)
     unsigned tiles_per_chan;         // ceil(n / fir_tile())
     int ntaps;
 };
@@ -36,17 +37,17 @@ struct BankRow {
 };
 
 int fir_tile();         // outputs per workgroup
-int fir_mfma_tile(int row_blocks);         // outputs per workgroup of the matrix-pipe variant (row_blocks = 2 or 4)
-int fir_mfma_bank_stride(int row_blocks);  // ... in bank mode
+int fir_mfma_tile();         // outputs per workgroup and tile of the matrix-pipe kernel
+int fir_mfma_bank_stride();  // ... in bank mode
 int fir_bank_stride();  // outputs per workgroup in bank mode
 
 hipError_t launch_fir_f64(const double* taps, const double* x, const double* hist, double* y, const FirShape& shape,
                           bool exact, bool vec2, hipStream_t stream);
 // Matrix-pipe (Toeplitz-block MFMA) variant of launch_fir_f64; tiles are fir_mfma_tile() outputs.
 hipError_t launch_fir_mfma_f64(const double* taps, const double* x, const double* hist, double* y,
-                               const FirShape& shape, int row_blocks, bool vec2, hipStream_t stream);
+                               const FirShape& shape, bool vec2, hipStream_t stream);
 hipError_t launch_fir_mfma_bank_f64(const double* taps, const BankRow* bank, const double* x, double* y,
-                                    const FirShape& shape, int row_blocks, bool vec2, hipStream_t stream);
+                                    const FirShape& shape, bool vec2, hipStream_t stream);
 // Bank mode: shape.n = length of the single input and of every output row, shape.y_stride = elements
 // between output rows, shape.tiles_per_chan = ceil(n / fir_bank_stride()), shape.total_tiles =
 // rows * 8 * ceil(tiles_per_chan / 8) workgroups (each row is cut into 8 runs of tiles, one per XCD; the

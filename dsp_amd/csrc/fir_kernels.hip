@@ -3,7 +3,7 @@
 // Computes y[i] = sum_j taps[j] * x[i-j] with taps ascending per output, i.e. the
 // inner loop of the reference lfilter (dsp.hpp:356-365) for a denominator of size 1,
 // with the samples before x[0] taken as zero (or from an explicit history buffer).
-// Two kernels: fir_f64_kernel on the vector pipe (described here) and fir_f64_mfma_kernel on
+// Two kernels: fir_f64_kernel on the vector pipe (described here) and fir_f64_mfma4_kernel on
 // the matrix pipe (described where it starts, further down).
 //
 // Work decomposition (vector pipe)
@@ -24,6 +24,9 @@
 // (80 bytes): 16-byte aligned for ds_read_b128 and conflict-free, because the 16 lanes
 // of a ds_read_b128 group start at 16 distinct multiples of 4 banks.
 #include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdlib>
 
 #include "fir_kernels.h"
 
@@ -283,292 +286,402 @@ __global__ __launch_bounds__(kBlock) void fir_f64_kernel(const double* __restric
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// Toeplitz-block variant on the FP64 matrix pipe (v_mfma_f64_16x16x4_f64).
-//
-// One wave computes 16 segments (matrix columns n) of 16*OB consecutive outputs each, as OB
-// 16-row blocks per segment (OB = 4 or 2).  For a tap offset d (a multiple of 4) the product
-//     D[m][n] += sum_k A[m][k] * B[k][n],   A[m][k] = taps[d + m - k],   B[k][n] = x[seg(n) + i0 - d + k]
-// adds, to output i0 + m of every segment, the four taps d+m-3 .. d+m.  A is the same 16x4
-// Toeplitz block for every segment and every i0 (one LDS read per step from a zero-padded copy
-// of the stage's taps); B is four consecutive input samples of each segment (one LDS read per
-// product, or per step where the operand ring of the four-block tiling reuses it across row blocks).  A filter of N taps takes floor((N+2)/4) + 4 steps: the band is N + 15 columns
-// wide instead of N, so 6 % of the multiplies are by zero at 255 taps and 0.4 % at 4095.
-//
-// Why it exists: on random data the chip holds ~2.39 GHz while issuing these products but only
-// ~1.9 GHz while issuing v_fma_f64 back to back, so the matrix pipe delivers more FP64 work
-// per second even after the zero multiplies (measured: tools/fp64_peak.hip).
-//
-// Differences from the vector kernel: within a step the four taps of an output are added in
-// descending order (steps ascend), so rounding differs slightly (same error bound).  The zero
-// taps at the band edges multiply real samples, and 0 * Inf is NaN; so a workgroup whose
-// staged window holds a non-finite sample computes its tile with a plain per-output FMA loop
-// instead, which adds exactly the products the reference adds.
-constexpr int kMHalo = 256;                     // staged samples in front of the tile
-constexpr int kMStageSteps = (kMHalo + 16) / 4; // steps of four tap offsets one staged window serves (68)
-constexpr int kMTapSlots = 4 * kMStageSteps + 24;
-// Geometry for OB row blocks of 16 outputs per segment (OB = 4: 4096-output tiles, fewest LDS
-// reads per product; OB = 2: 2048-output tiles, twice the workgroups per CU for short filters).
-template <int OB> struct MGeo {
-    static_assert(OB == 2 || OB == 4, "row blocks per segment");
-    static constexpr int kSeg = 16 * OB;                    // outputs per segment = pad group of the image
-    static constexpr int kPadStep = kSeg + 2;               // doubles between segments in the image
-    static constexpr int kShift = OB == 4 ? 6 : 5;          // log2(kSeg)
-    static constexpr int kWaveOut = 16 * kSeg;              // outputs per wave
-    static constexpr int kTile = (kBlock / 64) * kWaveOut;  // outputs per workgroup
-    static constexpr int kBankStride = kTile - 2;           // bank mode: two spare values of c per tile
-    static constexpr int kSlots = kMHalo + kTile;
-    static constexpr int kPairs = (kSlots + 2 * (kSlots / kSeg)) / 2;  // image: 2 pad doubles per segment length
-    static constexpr int kStageIters = (kSlots / 2 + kBlock - 1) / kBlock;
-};
-typedef double mfma_d4 __attribute__((ext_vector_type(4)));
+typedef double dvec2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ bool not_finite(double v) {
     return (__double_as_longlong(v) & 0x7ff0000000000000ll) == 0x7ff0000000000000ll;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Toeplitz-block variant on the FP64 matrix pipe, four-block form of the instruction (v_mfma_f64_4x4x4_4b_f64).
+//
+// Why it exists: on random data the chip holds its clock while issuing these products but drops to ~1.9 GHz while
+// issuing v_fma_f64 back to back, so the matrix pipe delivers more FP64 work per second (tools/fp64_peak.hip).
+//
+// One instruction multiplies four independent 4x4 blocks.  Operand layout (measured on gfx950 with one-hot
+// operands): A[i][k] of block b sits in lane i + 4b + 16k, B[k][j] in lane j + 4b + 16k, D[i][j] in lane
+// j + 4b + 16i, one double per lane each.  Here the 16 (block, j) pairs are the 16 segments of a wave
+// (n = lane & 15), i is one of four consecutive outputs and k one of four consecutive samples:
+//     D[i][n] += sum_k A[i][k] * B[k][n],   A[i][k] = taps[d + i - k],   B[k][n] = x[seg(n) + i0 - d + k]
+// adds the taps d+i-3 .. d+i to output i0 + i of every segment.  A is the same for all blocks and all i0 (one LDS
+// read per step of four tap offsets); the B operand of outputs i0 at offset d is the B operand of outputs i0 + 4
+// at offset d + 4, so a wave that owns RB row blocks of four outputs per segment reads ONE new sample vector per
+// step and keeps the RB - 1 before it in registers.  A filter of N taps takes floor((N + 2) / 4) + 1 steps: the
+// band is N + 3 columns wide (the 16x16x4 form of the instruction needs N + 15), and this form issues at its full
+// rate (one per 16 cycles and SIMD on random data, 76 TFLOP/s on the chip, against 66 for the 16x16x4 form).
+//
+// Differences from the vector kernel: within a step the four taps of an output are added in descending order
+// (steps ascend), so rounding differs slightly (same error bound), and which four taps share a step depends on an
+// output's distance from the start of its call modulo 4.
+//
+// Workgroups are persistent: the grid holds a few workgroups per CU and each walks its share of the tiles.  While the
+// products of one window run, the global loads of the next window (the next stage of a long filter, or the next
+// tile) are already in flight into registers; they are written to LDS when the products are done.  Results leave
+// through a second LDS buffer with plain stores nobody waits for.  Per window a workgroup meets at two barriers.
+template <int OB> struct M4Geo {
+    static constexpr int kSeg = 16 * OB;                    // outputs per segment (4 * OB row blocks of four) = pad group
+    static constexpr int kPadStep = kSeg + 2;               // doubles between segments in the image
+    static constexpr int kShift = OB == 4 ? 6 : 5;          // log2(kSeg)
+    static constexpr int kWaveOut = 16 * kSeg;              // outputs per wave
+    static constexpr int kTile = (kBlock / 64) * kWaveOut;  // outputs per workgroup and tile
+    static constexpr int kBankStride = kTile - 2;           // bank mode: two spare values of c per tile
+    static constexpr int kHalo = OB == 4 ? 320 : 288;       // image slots in front of the tile (a multiple of kSeg; sized so
+                                                            // that 2 resp. 4 workgroups fit the 160 KB of a CU)
+    static constexpr int kStageSteps = kHalo / 4 - 1;       // steps one window serves (79 / 71): the loop reads one step ahead
+    static constexpr int kTapSlots = 4 * kStageSteps + 8;   // likewise
+    static constexpr int kTapIters = (kTapSlots + kBlock - 1) / kBlock;
+    static constexpr int kSlots = kHalo + kTile;
+    static constexpr int kPairs = (kSlots + 2 * (kSlots / kSeg)) / 2;
+    static constexpr int kOutPairs = (kTile + 2 * (kTile / kSeg)) / 2;
+    static constexpr int kStageIters = (kSlots / 2 + kBlock - 1) / kBlock;
+    static constexpr int kResident = OB == 4 ? 2 : 4;       // workgroups per CU the grid is sized for
+    static_assert(kHalo % kSeg == 0, "the image's pad groups start at the window's first slot");
+    static_assert(kResident * (kPairs * 16 + kOutPairs * 16 + kTapSlots * 8 + 16) <= 160 * 1024, "LDS of the resident workgroups");
+};
+
+// What a workgroup needs to know about one tile (all wave-uniform).
+struct M4Tile {
+    const double* xc;
+    const double* hc;
+    const double* tapsc;
+    double* yrow;
+    long long tile_start, pos0;
+    double post;
+    int ntaps, odd;
+};
+
 template <int OB, bool VEC2, bool BANK>
-__global__ __launch_bounds__(kBlock) void fir_f64_mfma_kernel(const double* __restrict__ taps,
-                                                               const double* __restrict__ x,
-                                                               const double* __restrict__ hist,
-                                                               double* __restrict__ y,
-                                                               const BankRow* __restrict__ bank, FirShape s) {
-    using G = MGeo<OB>;
-    __shared__ double2 img[G::kPairs];
-    __shared__ double tapz[kMTapSlots];
-    __shared__ int bad_flag;
+__global__ __launch_bounds__(kBlock, OB == 4 ? 2 : 4) void fir_f64_mfma4_kernel(const double* __restrict__ taps,
+                                                                                 const double* __restrict__ x,
+                                                                                 const double* __restrict__ hist,
+                                                                                 double* __restrict__ y,
+                                                                                 const BankRow* __restrict__ bank,
+                                                                                 FirShape s) {
+    using G = M4Geo<OB>;
+    constexpr int RB = 4 * OB;  // row blocks of four outputs per segment
+    // One LDS block, the tap table first: LDS instructions reach 64 KB from their address register, and the product
+    // loop reads the table at constant distances from one pointer.
+    constexpr int kTapDoubles = (G::kTapSlots + 1) & ~1;
+    __shared__ double2 lds[kTapDoubles / 2 + G::kPairs + G::kOutPairs + 1];
+    double* const tapz = reinterpret_cast<double*>(lds);
+    double2* const img = lds + kTapDoubles / 2;
+    double2* const outb = img + G::kPairs;
+    int* const bad_flag = reinterpret_cast<int*>(outb + G::kOutPairs);
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
+    const long long n = s.n;
 
-    // tile assignment: as in fir_f64_kernel
-    const unsigned b = blockIdx.x;
-    const unsigned grp = b % 8, k8 = b / 8;
-    unsigned chan, tile;
+    // Blocks b and b + 8 share an XCD (and its L2): XCD g owns a contiguous run of tile indices, and its workgroups
+    // walk that run side by side (neighbouring tiles share a halo, which the XCD's L2 then serves).
+    const unsigned grp = blockIdx.x % 8, k8 = blockIdx.x / 8, per_xcd = gridDim.x / 8;
+    unsigned first, count;  // this XCD's tile indices: first .. first + count - 1 (bank mode: positions k of its runs)
     if constexpr (BANK) {
-        const unsigned run = (s.tiles_per_chan + 7) / 8;
-        chan = (unsigned)(((unsigned long long)k8 * s.div_magic) >> s.div_shift);
-        tile = grp * run + (k8 - chan * run);
-        if (tile >= s.tiles_per_chan) return;
+        first = 0, count = s.total_tiles / 8;  // rows * run positions; those past a row's last tile are skipped
     } else {
         const unsigned q8 = s.total_tiles / 8, r8 = s.total_tiles % 8;
-        const unsigned tile_id = (grp < r8 ? grp * (q8 + 1) : r8 * (q8 + 1) + (grp - r8) * q8) + k8;
-        chan = (unsigned)(((unsigned long long)tile_id * s.div_magic) >> s.div_shift);
-        tile = tile_id - chan * s.tiles_per_chan;
+        first = grp < r8 ? grp * (q8 + 1) : r8 * (q8 + 1) + (grp - r8) * q8;
+        count = q8 + (grp < r8 ? 1u : 0u);
     }
-    const long long n = s.n;
-    long long tile_start, pos0;
-    int ntaps, odd = 0;
-    double post = 1.0;
-    const double* __restrict__ xc;
-    const double* __restrict__ hc;
-    const double* __restrict__ tapsc;
-    double* __restrict__ yrow;
-    if constexpr (BANK) {
-        const BankRow row = bank[chan];
-        tile_start = (long long)tile * G::kBankStride;
-        odd = row.advance & 1;
-        pos0 = tile_start + row.advance - odd;
-        ntaps = row.ntaps;
-        post = row.scale;
-        xc = x, hc = nullptr;
-        tapsc = taps + row.taps_off;
-        yrow = y + row.out_off * s.y_stride;
-    } else {
-        tile_start = (long long)tile * G::kTile;
-        pos0 = tile_start;
-        ntaps = s.ntaps;
-        xc = x + (unsigned long long)chan * s.x_stride;
-        hc = hist ? hist + (unsigned long long)chan * s.hist_stride : nullptr;
-        tapsc = taps;
-        yrow = y + (unsigned long long)chan * s.y_stride;
-    }
-
-    mfma_d4 acc[OB];
-#pragma unroll
-    for (int ob = 0; ob < OB; ++ob) acc[ob] = mfma_d4{0.0, 0.0, 0.0, 0.0};
-    if (tid == 0) bad_flag = 0;
-
-    const double* imgd = reinterpret_cast<const double*>(img);
-    // lane (k = lane >> 4, n = lane & 15): image address of sample seg(n) + k, and tap slot of m - k at d = -12
-    const int b_base = (kMHalo + wave * G::kWaveOut) / G::kSeg * G::kPadStep + G::kPadStep * (lane & 15) + (lane >> 4);
-    const int a_base = 3 + (lane & 15) - (lane >> 4);
-    bool bad = false;
-
-    // Steps of four tap offsets (d = -12, -8, ...) that cover the whole band.  A stage is up to 68
-    // consecutive steps (what the staged halo reaches), an even number of them except in the last stage:
-    // it re-stages the samples those offsets reach and the taps d-3 .. d+15 they multiply, so stage
-    // boundaries cost no extra zero columns.
-    const int total_steps = ntaps ? (ntaps + 2) / 4 + 4 : 0;
-    const int nstages = (total_steps + kMStageSteps - 1) / kMStageSteps;
-    const int per_stage = nstages ? (((total_steps + nstages - 1) / nstages + 1) & ~1) : 0;  // even split, even count
-    for (int e0 = 0; e0 < total_steps; e0 += per_stage) {
-        const int steps = min(per_stage, total_steps - e0);
-        const int j0 = 4 * e0;  // the stage's first offset is d = j0 - 12
-        __syncthreads();  // previous stage fully consumed (and bad_flag initialised)
-        // tapz[i] = tap j0 - 15 + i (zero outside the filter)
-        for (int i = tid; i < kMTapSlots; i += kBlock) {
-            const int j = j0 - 15 + i;
-            tapz[i] = (j >= 0 && j < ntaps) ? tapsc[j] : 0.0;
-        }
-        // samples: slot q <- sample pos0 - j0 - kMHalo + q, from the lowest pad group the products read
-        const int qlo = (kMHalo - (4 * steps - 16)) & ~(G::kSeg - 1);
-        const int npairs = (G::kSlots - qlo) / 2;
-        const long long g_lo = pos0 - j0 - kMHalo + qlo;
-        double2* stage = img + (qlo >> 1) + (qlo >> G::kShift);
-        bool mine_bad = false;
-        if (g_lo >= 0 && g_lo + (G::kSlots - qlo) <= n) {  // interior tile: no edge tests
-            const double* __restrict__ src = xc + g_lo;
-#pragma unroll
-            for (int i = 0; i < G::kStageIters; ++i) {
-                const int pi = tid + i * kBlock;
-                if (i < G::kStageIters - 1 || pi < npairs) {
-                    double2 v;
-                    if constexpr (VEC2)
-                        v = reinterpret_cast<const double2*>(src)[pi];
-                    else
-                        v = make_double2(src[2 * pi], src[2 * pi + 1]);
-                    mine_bad = mine_bad || not_finite(v.x) || not_finite(v.y);
-                    stage[pi + (pi >> (G::kShift - 1))] = v;
-                }
-            }
-        } else {
-#pragma unroll 1
-            for (int pi = tid; pi < npairs; pi += kBlock) {
-                const double2 v = make_double2(sample_at(xc, hc, g_lo + 2 * pi, n, ntaps),
-                                               sample_at(xc, hc, g_lo + 2 * pi + 1, n, ntaps));
-                mine_bad = mine_bad || not_finite(v.x) || not_finite(v.y);
-                stage[pi + (pi >> (G::kShift - 1))] = v;
-            }
-        }
-        if (mine_bad) bad_flag = 1;
-        __syncthreads();
-        bad = bad_flag != 0;  // workgroup-uniform
-        if (bad) break;
-
-        // A sample vector read for row block 0 at step e is the operand of row block 1 at step e + 4, of block 2
-        // at e + 8, ...: iterations of 4*(OB-1) steps keep those in registers, so a step reads one new sample
-        // vector and one tap vector from LDS instead of OB + 1 (less LDS traffic: the chip is power-bound here,
-        // and the saving shows up as clock).
-        // Worth it with four row blocks (+1..3 %); with two it saves one read in three and costs ten registers
-        // (-0.5 %), so that tiling reads every operand from LDS in the loop further down.
-        constexpr int kRing = 4 * (OB - 1);
-        constexpr bool kUseRing = OB == 4;
-        auto sample_vec = [&](int off) { return imgd[b_base + off + 2 * (off >> G::kShift)]; };
-        double ring[kRing];  // ring[j] = the block-0 operand of step e - kRing + j
-        if constexpr (kUseRing) {
-#pragma unroll
-            for (int j = 0; j < kRing; ++j) ring[j] = sample_vec(12 + 4 * (kRing - j));
-        }
-        int e_first = 0;
-        for (; kUseRing && e_first + kRing <= steps; e_first += kRing) {
-            double f[kRing], a[kRing];
-#pragma unroll
-            for (int u = 0; u < kRing; ++u) {
-                f[u] = sample_vec(12 - 4 * (e_first + u));
-                a[u] = tapz[a_base + 4 * (e_first + u)];
-            }
-#pragma unroll
-            for (int u = 0; u < kRing; ++u) {
-#pragma unroll
-                for (int ob = 0; ob < OB; ++ob) {
-                    const double bv = u >= 4 * ob ? f[u - 4 * ob] : ring[kRing - 4 * ob + u];
-                    acc[ob] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], bv, acc[ob], 0, 0, 0);
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < kRing; ++j) ring[j] = f[j];
-        }
-        // the remaining steps (all of them without the ring), two per iteration with every operand read from LDS
-        for (int e = e_first; e + 1 < steps; e += 2) {
-            const double a0 = tapz[a_base + 4 * e];
-            const double a1 = tapz[a_base + 4 * e + 4];
-            double b0[OB], b1[OB];
-#pragma unroll
-            for (int ob = 0; ob < OB; ++ob) {
-                const int off0 = 16 * ob + 12 - 4 * e;   // i0 - d, a multiple of 4, may be negative
-                const int off1 = off0 - 4;
-                b0[ob] = imgd[b_base + off0 + 2 * (off0 >> G::kShift)];
-                b1[ob] = imgd[b_base + off1 + 2 * (off1 >> G::kShift)];
-            }
-#pragma unroll
-            for (int ob = 0; ob < OB; ++ob)
-                acc[ob] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0[ob], acc[ob], 0, 0, 0);
-#pragma unroll
-            for (int ob = 0; ob < OB; ++ob)
-                acc[ob] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1[ob], acc[ob], 0, 0, 0);
-        }
-        if ((steps - e_first) & 1) {  // the band's last step
-            const int e = steps - 1;
-            const double a0 = tapz[a_base + 4 * e];
-            double b0[OB];
-#pragma unroll
-            for (int ob = 0; ob < OB; ++ob) {
-                const int off0 = 16 * ob + 12 - 4 * e;
-                b0[ob] = imgd[b_base + off0 + 2 * (off0 >> G::kShift)];
-            }
-#pragma unroll
-            for (int ob = 0; ob < OB; ++ob)
-                acc[ob] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0[ob], acc[ob], 0, 0, 0);
-        }
-    }
-
-    double* __restrict__ yt = yrow + tile_start;
-    const long long left = n - tile_start;
-    constexpr int kOutputs = BANK ? G::kBankStride : G::kTile;
-
-    if (bad) {
-        // A non-finite sample is in reach of this tile: add exactly the products the reference adds,
-        // one output at a time (every sample comes from memory again; rare and slow by design).
-        const int extra = BANK ? 1 + odd : 0;  // bank mode needs c one or two samples past the tile
-        __syncthreads();
-        double* cbuf = reinterpret_cast<double*>(img);
-        for (int o = tid; o < kOutputs + extra + 1; o += kBlock) {
-            double sum = 0.0;
-            for (int j = 0; j < ntaps; ++j) {
-                const long long g = pos0 + o - j;
-                if (g >= 0 && g < n)
-                    sum = __builtin_fma(tapsc[j], xc[g], sum);
-                else if (g < 0 && hc != nullptr && g >= -(long long)(ntaps - 1))
-                    sum = __builtin_fma(tapsc[j], hc[(ntaps - 1) + g], sum);
-            }
-            cbuf[o] = sum;
-        }
-        __syncthreads();
-        for (int o = tid; o < kOutputs; o += kBlock) {
-            if (o < left) yt[o] = BANK ? (cbuf[o + odd + 1] - cbuf[o + odd]) * post : cbuf[o];
-        }
-        return;
-    }
-
-    // ---- accumulators -> LDS -> coalesced stores.  acc[ob][r] is output 16*ob + (lane >> 4) + 4r of segment lane & 15 ----
-    __syncthreads();
-    double* outd = reinterpret_cast<double*>(img);
-    const int o_base = wave * (G::kWaveOut / G::kSeg * G::kPadStep) + G::kPadStep * (lane & 15) + (lane >> 4);
-#pragma unroll
-    for (int ob = 0; ob < OB; ++ob) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) outd[o_base + 16 * ob + 4 * r] = acc[ob][r];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < G::kTile / 2 / kBlock; ++i) {
-        const int pi = tid + i * kBlock;
-        double2 o = img[pi + (pi >> (G::kShift - 1))];
+    // Fills `t` for position k of this XCD; false when there is no tile there.
+    auto locate = [&](unsigned k, M4Tile& t) __attribute__((always_inline)) -> bool {
+        if (k >= count) return false;
         if constexpr (BANK) {
-            // (c[i+1] - c[i]) * factor, shifted by one when the advance was rounded down
-            const int pn = min(pi + 1, G::kTile / 2 - 1);
-            const double2 c23 = img[pn + (pn >> (G::kShift - 1))];
-            o = odd ? make_double2((c23.x - o.y) * post, (c23.y - c23.x) * post)
-                    : make_double2((o.y - o.x) * post, (c23.x - o.y) * post);
-            if (2 * pi >= G::kBankStride) continue;
+            const unsigned run = (s.tiles_per_chan + 7) / 8;
+            const unsigned chan = (unsigned)(((unsigned long long)k * s.div_magic) >> s.div_shift);
+            const unsigned tile = grp * run + (k - chan * run);
+            if (tile >= s.tiles_per_chan) return false;
+            const BankRow row = bank[chan];
+            t.tile_start = (long long)tile * G::kBankStride;
+            t.odd = row.advance & 1;
+            t.pos0 = t.tile_start + row.advance - t.odd;
+            t.ntaps = row.ntaps;
+            t.post = row.scale;
+            t.xc = x, t.hc = nullptr;
+            t.tapsc = taps + row.taps_off;
+            t.yrow = y + row.out_off * s.y_stride;
+        } else {
+            const unsigned tile_id = first + k;
+            const unsigned chan = (unsigned)(((unsigned long long)tile_id * s.div_magic) >> s.div_shift);
+            const unsigned tile = tile_id - chan * s.tiles_per_chan;
+            t.tile_start = (long long)tile * G::kTile;
+            t.pos0 = t.tile_start;
+            t.ntaps = s.ntaps;
+            t.odd = 0, t.post = 1.0;
+            t.xc = x + (unsigned long long)chan * s.x_stride;
+            t.hc = hist ? hist + (unsigned long long)chan * s.hist_stride : nullptr;
+            t.tapsc = taps;
+            t.yrow = y + (unsigned long long)chan * s.y_stride;
         }
-        if (2 * pi + 1 < left) {
-            if constexpr (VEC2)
-                reinterpret_cast<double2*>(yt)[pi] = o;
-            else
-                yt[2 * pi] = o.x, yt[2 * pi + 1] = o.y;
-        } else if (2 * pi < left) {
-            yt[2 * pi] = o.x;
+        return true;
+    };
+    // Steps of four tap offsets d = 0, 4, ... cover the band; a window serves up to kStageSteps of them, longer
+    // filters take several windows (stages), split evenly.
+    auto stage_steps = [](int ntaps, int& total, int& per) __attribute__((always_inline)) {
+        total = ntaps ? (ntaps + 2) / 4 + 1 : 0;
+        const int nstages = (total + G::kStageSteps - 1) / G::kStageSteps;
+        per = nstages > 1 ? (total + nstages - 1) / nstages : max(total, 1);
+    };
+    // In lfilter mode a filter that fits one window keeps its tap table in LDS for the whole launch.
+    int total_steps, per_stage;
+    stage_steps(BANK ? 0 : s.ntaps, total_steps, per_stage);
+    const bool taps_stay = !BANK && total_steps <= per_stage;
+
+    // ---- the window in flight: samples (and taps) of (tile, first step e0) on their way into registers ----
+    // Image slot q <- sample pos0 - 4*e0 - kHalo + q, from the lowest pad group the products read; tap slot i <- tap
+    // 4*e0 - 3 + i (zero outside the filter).  A window that reaches outside [0, n) is not fetched ahead: commit()
+    // loads it with range checks (first and last windows of a channel; kept small, not fast).
+    dvec2 R[G::kStageIters];  // (a native vector type: struct copies of double2 would pin the array in scratch memory)
+    double T[G::kTapIters];
+    const unsigned lane_bytes = (unsigned)tid * 16u;
+    auto window_lo = [](int steps) __attribute__((always_inline)) { return (G::kHalo - 4 * (steps - 1)) & ~(G::kSeg - 1); };
+    auto is_interior = [&](const M4Tile& t, int e0, int steps) __attribute__((always_inline)) {
+        const int qlo = window_lo(steps);
+        const long long g_lo = t.pos0 - 4 * e0 - G::kHalo + qlo;
+        return g_lo >= 0 && g_lo + (G::kSlots - qlo) <= n;
+    };
+    auto fetch_taps = [&](const M4Tile& t, int e0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int r = 0; r < G::kTapIters; ++r) {
+            const int j = 4 * e0 - 3 + tid + r * kBlock;
+            T[r] = (j >= 0 && j < t.ntaps) ? t.tapsc[j] : 0.0;
+        }
+    };
+    auto fetch = [&](const M4Tile& t, int e0, int steps) __attribute__((always_inline)) {
+        if (!taps_stay) fetch_taps(t, e0);
+        if (!is_interior(t, e0, steps)) return;
+        const int qlo = window_lo(steps);
+        const int npairs = (G::kSlots - qlo) / 2;
+        const char* src = reinterpret_cast<const char*>(t.xc + (t.pos0 - 4 * e0 - G::kHalo + qlo));  // wave-uniform
+#pragma unroll
+        for (int i = 0; i < G::kStageIters; ++i) {
+            if (i < G::kStageIters - 1 || tid + i * kBlock < npairs) {
+                const char* p = src + (size_t)i * kBlock * 16 + lane_bytes;
+                if constexpr (VEC2)
+                    R[i] = *reinterpret_cast<const dvec2*>(p);
+                else
+                    R[i] = dvec2{reinterpret_cast<const double*>(p)[0], reinterpret_cast<const double*>(p)[1]};
+            }
+        }
+    };
+    const int stage_lane = tid + (tid >> (G::kShift - 1));  // where a thread's first pair goes, relative to the window's start
+    auto put_taps = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int r = 0; r < G::kTapIters; ++r) {
+            const int i = tid + r * kBlock;
+            if (r < G::kTapIters - 1 || i < G::kTapSlots) tapz[i] = T[r];
+        }
+    };
+    // registers -> LDS for the window fetch() was called for with the same arguments
+    auto commit = [&](const M4Tile& t, int e0, int steps) __attribute__((always_inline)) {
+        if (!taps_stay) put_taps();
+        const int qlo = window_lo(steps);
+        const int npairs = (G::kSlots - qlo) / 2;
+        dvec2* stage = reinterpret_cast<dvec2*>(img) + (qlo >> 1) + (qlo >> G::kShift) + stage_lane;
+        if (is_interior(t, e0, steps)) {
+#pragma unroll
+            for (int i = 0; i < G::kStageIters; ++i)  // pair tid + i*kBlock: a constant distance per i
+                if (i < G::kStageIters - 1 || tid + i * kBlock < npairs) stage[i * (kBlock + (kBlock >> (G::kShift - 1)))] = R[i];
+        } else {
+            const long long g_lo = t.pos0 - 4 * e0 - G::kHalo + qlo;
+#pragma unroll 1
+            for (int i = 0; tid + i * kBlock < npairs; ++i) {
+                const int pi = tid + i * kBlock;
+                stage[i * (kBlock + (kBlock >> (G::kShift - 1)))] =
+                    dvec2{sample_at(t.xc, t.hc, g_lo + 2 * pi, n, t.ntaps), sample_at(t.xc, t.hc, g_lo + 2 * pi + 1, n, t.ntaps)};
+            }
+        }
+    };
+
+    // lane (k = lane >> 4, n = lane & 15): image address of sample seg(n) + k, and tap slot of i - k at d = 0
+    const double* imgd = reinterpret_cast<const double*>(img);
+    const double* w_home = imgd + (G::kHalo + wave * G::kWaveOut) / G::kSeg * G::kPadStep + G::kPadStep * (lane & 15) + (lane >> 4);
+    const double* a_home = tapz + 3 + (lane & 3) - (lane >> 4);
+    // acc[rb] is output 4*rb + (lane >> 4) of segment lane & 15.  Segments 8..15 of a wave store every aligned pair of
+    // outputs swapped (index ^ 1): the 16 lanes of a ds_write_b64 group then fall into 16 different bank pairs
+    // (without it segments n and n + 8 collide), and a pair stays one aligned 16-byte unit for the readers, which
+    // swap it back.
+    double* o_home = reinterpret_cast<double*>(outb) + wave * (G::kWaveOut / G::kSeg * G::kPadStep) + G::kPadStep * (lane & 15) +
+                     ((lane >> 4) ^ ((lane >> 3) & 1));
+    const double2* g_home = outb + stage_lane;             // the pairs a thread stores to memory: tid + i*kBlock
+    const bool g_swap = OB == 2 && ((tid >> 7) & 1) != 0;  // OB == 4: pairs with odd i (compile-time)
+    if (tid < 2) bad_flag[tid] = 0;
+
+    // the first tile of this workgroup (positions k8, k8 + per_xcd, ... of the XCD's run)
+    M4Tile cur{};
+    unsigned k = k8;
+    bool have = false;
+    for (; k < count && !(have = locate(k, cur)); k += per_xcd) {}
+    if (!have) return;  // the whole workgroup leaves together
+    if constexpr (BANK) stage_steps(cur.ntaps, total_steps, per_stage);
+    if (taps_stay) {
+        fetch_taps(cur, 0);
+        put_taps();
+    }
+    fetch(cur, 0, min(per_stage, max(total_steps, 1)));
+
+    for (unsigned parity = 0; have; parity ^= 1u) {
+        // the tile after this one: located here and for the loads of its first window, and again when it becomes `cur`
+        // (cheaper than carrying its description through the products)
+        bool have_next = false;
+        unsigned kn = k + per_xcd;
+        {
+            M4Tile nxt{};
+            for (; kn < count && !(have_next = locate(kn, nxt)); kn += per_xcd) {}
+        }
+
+        double acc[RB];
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) acc[rb] = 0.0;
+
+        int e0 = 0;
+        do {  // windows of this tile (one unless the filter is longer than a window reaches; none of zero taps: one, idle)
+            const int steps = min(per_stage, max(total_steps, 1) - e0);
+            commit(cur, e0, steps);  // everybody is past the previous window's products (barriers below)
+            // start the loads of the window after this one
+            const int e_next = e0 + steps;
+            if (e_next < total_steps) {
+                fetch(cur, e_next, min(per_stage, total_steps - e_next));
+            } else if (have_next) {
+                M4Tile nxt{};
+                (void)locate(kn, nxt);
+                int next_total = total_steps, next_per = per_stage;
+                if constexpr (BANK) stage_steps(nxt.ntaps, next_total, next_per);
+                fetch(nxt, 0, min(next_per, max(next_total, 1)));
+            }
+            __syncthreads();
+
+            if (total_steps > 0) {
+                // V(s) = the four-sample vector at offset -4s from the lane's segment start: w_home[-4s], two doubles
+                // lower for every pad group crossed.  Row block rb uses V(el - rb) at step el.  w[] is a circular window
+                // over them, V(s) in slot s mod RB: a step runs its row blocks from the last to the first, so the slot the
+                // oldest vector leaves is refilled (for the next step's row block 0) right after its last use, a whole
+                // step ahead of its first.  Steps run in groups of RB: within a group every refill V(el + u + 1) lies in
+                // one pad group, so a group reads at constant distances from one pointer that moves by kPadStep per group.
+                double w[RB];
+#pragma unroll
+                for (int j = 1; j < RB; ++j) w[j] = w_home[4 * (RB - j)];
+                w[0] = w_home[0];
+                const double* wp = w_home - G::kPadStep;  // V(el + u + 1) = wp[kSeg - 4*(u + 1)] for the group at el
+                const double* ap = a_home;                // tap vector of step el + u = ap[4*u]
+                double a_now = ap[0];
+                int el = 0;
+                for (; el + RB <= steps; el += RB, wp -= G::kPadStep, ap += 4 * RB) {
+#pragma unroll
+                    for (int u = 0; u < RB; ++u) {
+                        const double a = a_now;
+                        a_now = ap[4 * (u + 1)];  // the table has a spare step past the last
+#pragma unroll
+                        for (int rb = RB - 1; rb >= 0; --rb) {
+                            acc[rb] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, w[(u - rb + RB) % RB], acc[rb], 0, 0, 0);
+                            if (rb == RB - 1) w[(u + 1) % RB] = wp[G::kSeg - 4 * (u + 1)];  // at most one step past the window: in the image
+                        }
+                        __builtin_amdgcn_sched_barrier(0);  // keep every step's two LDS reads in their step (a step ahead of their use)
+                    }
+                }
+                if (el < steps) {  // the window's last steps, fewer than RB of them (wave-uniform branches)
+                    const int rem = steps - el;
+#pragma unroll
+                    for (int u = 0; u < RB - 1; ++u) {
+                        if (u < rem) {
+                            const double a = a_now;
+                            a_now = ap[4 * (u + 1)];
+#pragma unroll
+                            for (int rb = RB - 1; rb >= 0; --rb) {
+                                acc[rb] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, w[(u - rb + RB) % RB], acc[rb], 0, 0, 0);
+                                if (rb == RB - 1) w[(u + 1) % RB] = wp[G::kSeg - 4 * (u + 1)];
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                }
+            }
+            e0 = e_next;
+            if (e0 < total_steps) __syncthreads();  // the image is rewritten for the next window
+        } while (e0 < total_steps);
+
+        // ---- accumulators -> second LDS buffer ----
+        // The zero taps at the band's edges multiply real samples and the zero samples in front of a channel multiply
+        // real taps; 0 * Inf (or NaN) is NaN where the reference adds nothing.  Any such product leaves a non-finite
+        // accumulator, and then so is the sum of the lane's accumulators: a tile with one is computed again by the plain
+        // loop below, which adds exactly the reference's products.  (A sum of finite values that overflows only sends
+        // a tile there needlessly.)
+        double probe = acc[0];
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+            if (rb) probe += acc[rb];
+            o_home[4 * rb] = acc[rb];
+        }
+        if (not_finite(probe)) bad_flag[parity] = 1;
+        __syncthreads();  // also: everybody is past this tile's products
+        const bool bad = bad_flag[parity] != 0;  // workgroup-uniform
+        if (tid == 0) bad_flag[parity ^ 1u] = 0;  // not written again before the next tile's barriers
+
+        double* __restrict__ yt = cur.yrow + cur.tile_start;
+        const long long left = n - cur.tile_start;
+        constexpr int kOutputs = BANK ? G::kBankStride : G::kTile;
+        if (bad) {
+            // one output at a time, every sample from memory again (rare and slow by design)
+            double* outd = reinterpret_cast<double*>(outb);
+            const int extra = BANK ? 1 + cur.odd : 0;  // bank mode needs c one or two samples past the tile
+            __syncthreads();
+            for (int o = tid; o < kOutputs + extra + 1; o += kBlock) {
+                double sum = 0.0;
+                for (int j = 0; j < cur.ntaps; ++j) {
+                    const long long g = cur.pos0 + o - j;
+                    if (g >= 0 && g < n)
+                        sum = __builtin_fma(cur.tapsc[j], cur.xc[g], sum);
+                    else if (g < 0 && cur.hc != nullptr && g >= -(long long)(cur.ntaps - 1))
+                        sum = __builtin_fma(cur.tapsc[j], cur.hc[(cur.ntaps - 1) + g], sum);
+                }
+                outd[o] = sum;
+            }
+            __syncthreads();
+            for (int o = tid; o < kOutputs; o += kBlock) {
+                if (o < left) yt[o] = BANK ? (outd[o + cur.odd + 1] - outd[o + cur.odd]) * cur.post : outd[o];
+            }
+            __syncthreads();  // the buffer is free for the next tile
+        } else {
+            constexpr int kPairStep = kBlock + (kBlock >> (G::kShift - 1));  // image distance of pairs kBlock apart
+            auto out_pair = [&](int i) __attribute__((always_inline)) {  // outputs 2*pi, 2*pi + 1 of the tile, pi = tid + i*kBlock
+                const double2 v = g_home[i * kPairStep];
+                const bool swapped = OB == 4 ? (i & 1) != 0 : g_swap;
+                return swapped ? make_double2(v.y, v.x) : v;
+            };
+            char* dst = reinterpret_cast<char*>(yt);  // wave-uniform
+            const bool whole = !BANK && left >= G::kTile;
+#pragma unroll
+            for (int i = 0; i < G::kTile / 2 / kBlock; ++i) {
+                const int pi = tid + i * kBlock;
+                double2 o = out_pair(i);
+                if constexpr (BANK) {
+                    // (c[i+1] - c[i]) * factor, shifted by one when the advance was rounded down
+                    double2 c23;
+                    if (i + 1 < G::kTile / 2 / kBlock || tid + 1 < kBlock) {
+                        const int pn = pi + 1;
+                        const double2 v = outb[pn + (pn >> (G::kShift - 1))];
+                        c23 = ((pn >> (G::kShift - 1)) & 8) ? make_double2(v.y, v.x) : v;
+                    } else {
+                        c23 = o;  // the tile's last pair is never stored
+                    }
+                    o = cur.odd ? make_double2((c23.x - o.y) * cur.post, (c23.y - c23.x) * cur.post)
+                                : make_double2((o.y - o.x) * cur.post, (c23.x - o.y) * cur.post);
+                    if (2 * pi >= G::kBankStride) continue;
+                }
+                char* p = dst + (size_t)i * kBlock * 16 + lane_bytes;
+                if (whole || 2 * pi + 1 < left) {
+                    if constexpr (VEC2)
+                        *reinterpret_cast<double2*>(p) = o;
+                    else
+                        reinterpret_cast<double*>(p)[0] = o.x, reinterpret_cast<double*>(p)[1] = o.y;
+                } else if (2 * pi < left) {
+                    reinterpret_cast<double*>(p)[0] = o.x;
+                }
+            }
+        }
+        k = kn, have = have_next;
+        if (have) {
+            (void)locate(k, cur);
+            if constexpr (BANK) stage_steps(cur.ntaps, total_steps, per_stage);
         }
     }
 }
@@ -607,39 +720,48 @@ __global__ __launch_bounds__(256) void checksum_kernel(const double* __restrict_
 
 }  // namespace
 
-int fir_tile() { return kTile; }
-int fir_mfma_tile(int row_blocks) { return row_blocks == 2 ? MGeo<2>::kTile : MGeo<4>::kTile; }
-int fir_mfma_bank_stride(int row_blocks) { return row_blocks == 2 ? MGeo<2>::kBankStride : MGeo<4>::kBankStride; }
+// Row blocks of 16 outputs per segment of the matrix-pipe kernel.  2 (2048-output tiles, four workgroups per CU)
+// measured faster than 4 (4096-output tiles, two per CU) at every tap count from 63 to 4095.
+constexpr int kMatrixOB = 2;
 
-template <int OB, bool BANK>
+int fir_tile() { return kTile; }
+int fir_mfma_tile() { return M4Geo<kMatrixOB>::kTile; }
+int fir_mfma_bank_stride() { return M4Geo<kMatrixOB>::kBankStride; }
+
+// Compute units of the current device (256 on MI355X); queried once per device.
+static unsigned compute_units() {
+    static unsigned cached[64] = {};
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (cached[dev]) return cached[dev];
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    return cached[dev] = (unsigned)cus;
+}
+
+template <bool BANK>
 static void launch_mfma_variant(const double* taps, const double* x, const double* hist, double* y, const BankRow* bank,
                                 const FirShape& shape, bool vec2, hipStream_t stream) {
-    const dim3 grid(shape.total_tiles), block(kBlock);
+    // persistent workgroups: a few per CU, in multiples of 8 (one share per XCD), never more than there are tiles
+    using G = M4Geo<kMatrixOB>;
+    const unsigned per_xcd = std::min((shape.total_tiles + 7) / 8, compute_units() * G::kResident / 8);
+    const dim3 grid(8 * std::max(per_xcd, 1u)), block(kBlock);
     if (vec2)
-        hipLaunchKernelGGL((fir_f64_mfma_kernel<OB, true, BANK>), grid, block, 0, stream, taps, x, hist, y, bank, shape);
+        hipLaunchKernelGGL((fir_f64_mfma4_kernel<kMatrixOB, true, BANK>), grid, block, 0, stream, taps, x, hist, y, bank, shape);
     else
-        hipLaunchKernelGGL((fir_f64_mfma_kernel<OB, false, BANK>), grid, block, 0, stream, taps, x, hist, y, bank, shape);
+        hipLaunchKernelGGL((fir_f64_mfma4_kernel<kMatrixOB, false, BANK>), grid, block, 0, stream, taps, x, hist, y, bank, shape);
 }
 
 hipError_t launch_fir_mfma_f64(const double* taps, const double* x, const double* hist, double* y,
-                               const FirShape& shape, int row_blocks, bool vec2, hipStream_t stream) {
+                               const FirShape& shape, bool vec2, hipStream_t stream) {
     if (shape.total_tiles == 0) return hipSuccess;
-    if (!grid_fits(shape.total_tiles)) return hipErrorInvalidConfiguration;
-    if (row_blocks == 2)
-        launch_mfma_variant<2, false>(taps, x, hist, y, nullptr, shape, vec2, stream);
-    else
-        launch_mfma_variant<4, false>(taps, x, hist, y, nullptr, shape, vec2, stream);
+    launch_mfma_variant<false>(taps, x, hist, y, nullptr, shape, vec2, stream);
     return hipGetLastError();
 }
 
 hipError_t launch_fir_mfma_bank_f64(const double* taps, const BankRow* bank, const double* x, double* y,
-                                    const FirShape& shape, int row_blocks, bool vec2, hipStream_t stream) {
+                                    const FirShape& shape, bool vec2, hipStream_t stream) {
     if (shape.total_tiles == 0) return hipSuccess;
-    if (!grid_fits(shape.total_tiles)) return hipErrorInvalidConfiguration;
-    if (row_blocks == 2)
-        launch_mfma_variant<2, true>(taps, x, nullptr, y, bank, shape, vec2, stream);
-    else
-        launch_mfma_variant<4, true>(taps, x, nullptr, y, bank, shape, vec2, stream);
+    launch_mfma_variant<true>(taps, x, nullptr, y, bank, shape, vec2, stream);
     return hipGetLastError();
 }
 
@@ -705,3 +827,4 @@ hipError_t launch_checksum(const double* yv, unsigned long long n, unsigned long
 }
 
 }  // namespace dspx
+

@@ -70,8 +70,7 @@ def test_pipe_thresholds_mirror_the_library(dsp):
     """The constants the benchmark labels its kernels by are the ones the library selects pipes with."""
     src = open(os.path.join(ROOT, "dsp_amd", "csrc", "dspx_common.h")).read()
     lo = int(re.search(r"kMatrixPipeMinTaps\s*=\s*(\d+)", src).group(1))
-    hi = int(re.search(r"kMatrixPipeWideTaps\s*=\s*(\d+)", src).group(1))
-    assert (dsp.MATRIX_PIPE_MIN_TAPS, dsp.MATRIX_PIPE_WIDE_TAPS) == (lo, hi)
+    assert dsp.MATRIX_PIPE_MIN_TAPS == lo
 
 
 def test_product_does_not_import_the_oracle():

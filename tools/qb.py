@@ -10,7 +10,7 @@ import torch
 
 import dsp_amd
 
-W = {"b255": (4096, 1 << 20, 255), "l101": (1, 1 << 28, 101), "l4095": (1, 1 << 26, 4095), "b255s": (256, 1 << 20, 255),
+W = {"b255": (4096, 1 << 20, 255), "l101": (1, 1 << 28, 101), "l4095": (1, 1 << 26, 4095), "b255s": (256, 1 << 20, 255), "b251": (1024, 1 << 20, 251), "b315": (1024, 1 << 20, 315), "b187": (1024, 1 << 20, 187), "b123": (1024, 1 << 20, 123), "b59": (1024, 1 << 20, 59),
      "b31": (1024, 1 << 20, 31), "b63": (1024, 1 << 20, 63), "b1023": (256, 1 << 20, 1023), "b101": (2048, 1 << 20, 101), "b256": (4096, 1 << 20, 256), "b240": (4096, 1 << 20, 240), "b512": (2048, 1 << 20, 512),
      "b96": (2048, 1 << 20, 96), "b128": (2048, 1 << 20, 128), "b160": (2048, 1 << 20, 160), "b192": (2048, 1 << 20, 192),
      "b144": (2048, 1 << 20, 144), "b300": (2048, 1 << 20, 300), "b112": (2048, 1 << 20, 112), "b80": (2048, 1 << 20, 80), "b224": (2048, 1 << 20, 224), "b208": (2048, 1 << 20, 208), "b48": (2048, 1 << 20, 48), "b2": (4096, 1 << 20, 2), "b8": (4096, 1 << 20, 8), "b16": (4096, 1 << 20, 16), "b24": (4096, 1 << 20, 24)}
