@@ -66,6 +66,17 @@ template <bool EXACT> __device__ __forceinline__ double mac(double b, double w, 
     }
 }
 
+typedef double dvec2 __attribute__((ext_vector_type(2)));
+
+// 16-byte accesses to data that is read or written once per launch carry the non-temporal hint (measured on
+// MI355X: a 2-tap filter, i.e. a scaled copy, moves 6.23 TB/s with it and 6.00 without).
+__device__ __forceinline__ dvec2 stream_load(const dvec2* p) { return __builtin_nontemporal_load(p); }
+__device__ __forceinline__ void stream_store(dvec2* p, dvec2 v) { __builtin_nontemporal_store(v, p); }
+
+__device__ __forceinline__ bool not_finite(double v) {
+    return (__double_as_longlong(v) & 0x7ff0000000000000ll) == 0x7ff0000000000000ll;
+}
+
 // One input sample of a channel at signed position g: history (or zero) before the
 // channel start, zero past its end.
 __device__ __forceinline__ double sample_at(const double* __restrict__ xc, const double* __restrict__ hc,
@@ -163,6 +174,7 @@ __global__ __launch_bounds__(kBlock) void fir_f64_kernel(const double* __restric
     double acc[kR];
 #pragma unroll
     for (int r = 0; r < kR; ++r) acc[r] = 0.0;
+    bool edge = false;  // some window of this tile reached outside the channel (workgroup-uniform)
 
     for (int j0 = 0; j0 < ntaps; j0 += kStageTaps) {
         const int S = min(kStageTaps, ntaps - j0);
@@ -177,22 +189,24 @@ __global__ __launch_bounds__(kBlock) void fir_f64_kernel(const double* __restric
         double2* stage = lds + pair_of(qlo) + stage_pair;
         if (g_lo >= 0 && g_lo + (kSlots - qlo) <= n) {  // interior tile (workgroup-uniform): no edge tests
             const double* __restrict__ src = xc + g_lo;
-            double2 v[kStageIters];
+            dvec2 v[kStageIters];
 #pragma unroll
             for (int i = 0; i < kStageIters; ++i) {
                 const int pi = tid + i * kBlock;
                 if (i < kStageIters - 1 || pi < npairs) {
-                    if constexpr (VEC2)
-                        v[i] = reinterpret_cast<const double2*>(src)[pi];
+                    if constexpr (VEC2)  // samples that this launch reads once (one stage, one row) are streamed
+                        v[i] = (!BANK && ntaps <= kStageTaps) ? stream_load(reinterpret_cast<const dvec2*>(src) + pi)
+                                                              : reinterpret_cast<const dvec2*>(src)[pi];
                     else
-                        v[i] = make_double2(src[2 * pi], src[2 * pi + 1]);
+                        v[i] = dvec2{src[2 * pi], src[2 * pi + 1]};
                 }
             }
 #pragma unroll
             for (int i = 0; i < kStageIters; ++i) {
-                if (i < kStageIters - 1 || tid + i * kBlock < npairs) stage[i * pair_of(2 * kBlock)] = v[i];
+                if (i < kStageIters - 1 || tid + i * kBlock < npairs) reinterpret_cast<dvec2*>(stage)[i * pair_of(2 * kBlock)] = v[i];
             }
         } else {  // first / last tiles of a channel: every sample is range-checked (kept small, not fast)
+            edge = true;
 #pragma unroll 1
             for (int i = 0; i < kStageIters; ++i) {
                 const int pi = tid + i * kBlock;
@@ -235,6 +249,31 @@ __global__ __launch_bounds__(kBlock) void fir_f64_kernel(const double* __restric
         }
     }
 
+    // The zeros staged for samples outside the channel were multiplied by real taps, and 0 * Inf (or NaN) is NaN
+    // where the reference, which never multiplies a missing sample (dsp.hpp:359-364), adds nothing.  Only a
+    // non-finite tap does that, and it leaves a non-finite accumulator: such outputs are summed again over the
+    // samples that exist, in the same order.
+    if (edge) {
+        bool redo = false;
+#pragma unroll
+        for (int r = 0; r < kR; ++r) redo = redo || not_finite(acc[r]);
+        if (redo) {
+#pragma unroll 1
+            for (int r = 0; r < kR; ++r) {
+                const long long p = pos0 + kR * tid + r;
+                double sum = 0.0;
+                for (int j = 0; j < ntaps; ++j) {
+                    const long long g = p - j;
+                    if (g >= 0 && g < n)
+                        sum = mac<EXACT>(tapsc[j], xc[g], sum);
+                    else if (g < 0 && hc != nullptr && g >= -(long long)(ntaps - 1))
+                        sum = mac<EXACT>(tapsc[j], hc[(ntaps - 1) + g], sum);
+                }
+                acc[r] = sum;
+            }
+        }
+    }
+
     // ---- store the tile: accumulators -> LDS (stride 5 pairs) -> coalesced 16-byte stores ----
     __syncthreads();
 #pragma unroll
@@ -271,7 +310,7 @@ __global__ __launch_bounds__(kBlock) void fir_f64_kernel(const double* __restric
             const double2 o = back[i * pair_of(2 * kBlock)];
             if (left >= kTile) {  // full tile (workgroup-uniform)
                 if constexpr (VEC2)
-                    reinterpret_cast<double2*>(yt)[pi] = o;
+                    stream_store(reinterpret_cast<dvec2*>(yt) + pi, dvec2{o.x, o.y});
                 else
                     yt[2 * pi] = o.x, yt[2 * pi + 1] = o.y;
             } else if (2 * pi + 1 < left) {
@@ -284,12 +323,6 @@ __global__ __launch_bounds__(kBlock) void fir_f64_kernel(const double* __restric
             }
         }
     }
-}
-
-typedef double dvec2 __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ bool not_finite(double v) {
-    return (__double_as_longlong(v) & 0x7ff0000000000000ll) == 0x7ff0000000000000ll;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -456,8 +489,8 @@ __global__ __launch_bounds__(kBlock, OB == 4 ? 2 : 4) void fir_f64_mfma4_kernel(
         for (int i = 0; i < G::kStageIters; ++i) {
             if (i < G::kStageIters - 1 || tid + i * kBlock < npairs) {
                 const char* p = src + (size_t)i * kBlock * 16 + lane_bytes;
-                if constexpr (VEC2)
-                    R[i] = *reinterpret_cast<const dvec2*>(p);
+                if constexpr (VEC2)  // a long filter reads its samples once per window: those loads stay cacheable
+                    R[i] = taps_stay ? stream_load(reinterpret_cast<const dvec2*>(p)) : *reinterpret_cast<const dvec2*>(p);
                 else
                     R[i] = dvec2{reinterpret_cast<const double*>(p)[0], reinterpret_cast<const double*>(p)[1]};
             }
@@ -670,7 +703,7 @@ __global__ __launch_bounds__(kBlock, OB == 4 ? 2 : 4) void fir_f64_mfma4_kernel(
                 char* p = dst + (size_t)i * kBlock * 16 + lane_bytes;
                 if (whole || 2 * pi + 1 < left) {
                     if constexpr (VEC2)
-                        *reinterpret_cast<double2*>(p) = o;
+                        stream_store(reinterpret_cast<dvec2*>(p), dvec2{o.x, o.y});
                     else
                         reinterpret_cast<double*>(p)[0] = o.x, reinterpret_cast<double*>(p)[1] = o.y;
                 } else if (2 * pi < left) {

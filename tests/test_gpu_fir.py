@@ -284,6 +284,27 @@ def test_nan_inf_samples_stay_local(dsp, oracle):
         assert scaled_err(yl[ok], refl[ok]) <= TOL
 
 
+@pytest.mark.parametrize("ntaps,where", [(31, 5), (31, 30), (255, 100), (255, 254), (255, 0)])
+def test_non_finite_taps_follow_the_reference(dsp, oracle, ntaps, where):
+    """An Inf or NaN tap: the reference's truncated sums at the start of a stream never multiply a sample that does
+    not exist (dsp.hpp:359-364), so the first `where` outputs stay finite there -- and here, on both pipes and in
+    exact mode (bit for bit); the same at the start of every channel.  (A history buffer holds real samples, zeros
+    included: the streaming entry points multiply them like any other sample.)"""
+    for bad in (np.inf, np.nan):
+        b = oracle.firwin(ntaps, [0.25]).copy()
+        b[where] = bad
+        x = np.stack([oracle.fill_splitmix(9000, 9, c) for c in range(2)])
+        ref = np.stack([oracle.lfilter(b, [1.0], x[c]) for c in range(2)])
+        assert np.isfinite(ref[:, :where]).all() and not np.isfinite(ref[:, where:]).any()
+        for exact, pipe in ((True, None), (False, False), (False, True), (False, None)):
+            y = dsp.lfilter(b, x, exact=exact, mfma=pipe)
+            assert np.array_equal(np.isfinite(y), np.isfinite(ref)), (bad, exact, pipe)
+            if where:
+                assert scaled_err(y[:, :where], ref[:, :where]) <= TOL
+            if exact:
+                assert np.array_equal(bits(y), bits(ref))
+
+
 @pytest.mark.parametrize("ntaps", [1, 2, 33, 255])
 def test_streaming_chunks_reproduce_one_call(dsp, oracle, ntaps):
     """dspx_fir_f64_stream: history carried between chunks (also chunks shorter than the filter)."""
