@@ -459,19 +459,16 @@ __global__ __launch_bounds__(kBlock, OB == 4 ? 2 : 4) void fir_f64_mfma4_kernel(
     stage_steps(BANK ? 0 : s.ntaps, total_steps, per_stage);
     const bool taps_stay = !BANK && total_steps <= per_stage;
 
-    // ---- the window in flight: samples (and taps) of (tile, first step e0) on their way into registers ----
-    // Image slot q <- sample pos0 - 4*e0 - kHalo + q, from the lowest pad group the products read; tap slot i <- tap
-    // 4*e0 - 3 + i (zero outside the filter).  A window that reaches outside [0, n) is not fetched ahead: commit()
-    // loads it with range checks (first and last windows of a channel; kept small, not fast).
-    dvec2 R[G::kStageIters];  // (a native vector type: struct copies of double2 would pin the array in scratch memory)
+    // ---- the window in flight: samples (and taps) of (tile at position fk, first step fe0) on their way into
+    // registers.  Image slot q <- sample pos0 - 4*e0 - kHalo + q, from the lowest pad group the products read; tap
+    // slot i <- tap 4*e0 - 3 + i (zero outside the filter).  A window that reaches outside [0, n) is not fetched
+    // ahead: commit() loads it with range checks (first and last windows of a channel; kept small, not fast).
+    dvec2 R[G::kStageIters];
     double T[G::kTapIters];
-    const unsigned lane_bytes = (unsigned)tid * 16u;
+    unsigned fk = 0;
+    int fe0 = 0, fsteps = 1;
+    bool finterior = false;
     auto window_lo = [](int steps) __attribute__((always_inline)) { return (G::kHalo - 4 * (steps - 1)) & ~(G::kSeg - 1); };
-    auto is_interior = [&](const M4Tile& t, int e0, int steps) __attribute__((always_inline)) {
-        const int qlo = window_lo(steps);
-        const long long g_lo = t.pos0 - 4 * e0 - G::kHalo + qlo;
-        return g_lo >= 0 && g_lo + (G::kSlots - qlo) <= n;
-    };
     auto fetch_taps = [&](const M4Tile& t, int e0) __attribute__((always_inline)) {
 #pragma unroll
         for (int r = 0; r < G::kTapIters; ++r) {
@@ -479,24 +476,30 @@ __global__ __launch_bounds__(kBlock, OB == 4 ? 2 : 4) void fir_f64_mfma4_kernel(
             T[r] = (j >= 0 && j < t.ntaps) ? t.tapsc[j] : 0.0;
         }
     };
-    auto fetch = [&](const M4Tile& t, int e0, int steps) __attribute__((always_inline)) {
+    auto fetch = [&](const M4Tile& t, unsigned kpos, int e0, int steps) __attribute__((always_inline)) {
+        fk = kpos, fe0 = e0, fsteps = steps;
         if (!taps_stay) fetch_taps(t, e0);
-        if (!is_interior(t, e0, steps)) return;
         const int qlo = window_lo(steps);
+        const long long g_lo = t.pos0 - 4 * e0 - G::kHalo + qlo;
+        finterior = g_lo >= 0 && g_lo + (G::kSlots - qlo) <= n;
+        if (!finterior) return;
         const int npairs = (G::kSlots - qlo) / 2;
-        const char* src = reinterpret_cast<const char*>(t.xc + (t.pos0 - 4 * e0 - G::kHalo + qlo));  // wave-uniform
+        const double* src = t.xc + g_lo;  // wave-uniform
 #pragma unroll
         for (int i = 0; i < G::kStageIters; ++i) {
             if (i < G::kStageIters - 1 || tid + i * kBlock < npairs) {
-                const char* p = src + (size_t)i * kBlock * 16 + lane_bytes;
-                if constexpr (VEC2)  // a long filter reads its samples once per window: those loads stay cacheable
-                    R[i] = taps_stay ? stream_load(reinterpret_cast<const dvec2*>(p)) : *reinterpret_cast<const dvec2*>(p);
-                else
-                    R[i] = dvec2{reinterpret_cast<const double*>(p)[0], reinterpret_cast<const double*>(p)[1]};
+                if constexpr (VEC2) {  // a long filter reads its samples once per window: those loads stay cacheable
+                    const dvec2* p = reinterpret_cast<const dvec2*>(src) + i * kBlock;
+                    R[i] = taps_stay ? stream_load(p + (unsigned)tid) : p[(unsigned)tid];
+                } else {
+                    const double* p = src + 2 * i * kBlock;
+                    R[i] = dvec2{p[2u * (unsigned)tid], p[2u * (unsigned)tid + 1u]};
+                }
             }
         }
     };
     const int stage_lane = tid + (tid >> (G::kShift - 1));  // where a thread's first pair goes, relative to the window's start
+    constexpr int kPairStep = kBlock + (kBlock >> (G::kShift - 1));  // image distance of pairs kBlock apart
     auto put_taps = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int r = 0; r < G::kTapIters; ++r) {
@@ -504,22 +507,24 @@ __global__ __launch_bounds__(kBlock, OB == 4 ? 2 : 4) void fir_f64_mfma4_kernel(
             if (r < G::kTapIters - 1 || i < G::kTapSlots) tapz[i] = T[r];
         }
     };
-    // registers -> LDS for the window fetch() was called for with the same arguments
-    auto commit = [&](const M4Tile& t, int e0, int steps) __attribute__((always_inline)) {
+    // registers -> LDS for the window in flight
+    auto commit = [&]() __attribute__((always_inline)) {
         if (!taps_stay) put_taps();
-        const int qlo = window_lo(steps);
+        const int qlo = window_lo(fsteps);
         const int npairs = (G::kSlots - qlo) / 2;
         dvec2* stage = reinterpret_cast<dvec2*>(img) + (qlo >> 1) + (qlo >> G::kShift) + stage_lane;
-        if (is_interior(t, e0, steps)) {
+        if (finterior) {
 #pragma unroll
             for (int i = 0; i < G::kStageIters; ++i)  // pair tid + i*kBlock: a constant distance per i
-                if (i < G::kStageIters - 1 || tid + i * kBlock < npairs) stage[i * (kBlock + (kBlock >> (G::kShift - 1)))] = R[i];
+                if (i < G::kStageIters - 1 || tid + i * kBlock < npairs) stage[i * kPairStep] = R[i];
         } else {
-            const long long g_lo = t.pos0 - 4 * e0 - G::kHalo + qlo;
+            M4Tile t{};
+            (void)locate(fk, t);
+            const long long g_lo = t.pos0 - 4 * fe0 - G::kHalo + qlo;
 #pragma unroll 1
             for (int i = 0; tid + i * kBlock < npairs; ++i) {
                 const int pi = tid + i * kBlock;
-                stage[i * (kBlock + (kBlock >> (G::kShift - 1)))] =
+                stage[i * kPairStep] =
                     dvec2{sample_at(t.xc, t.hc, g_lo + 2 * pi, n, t.ntaps), sample_at(t.xc, t.hc, g_lo + 2 * pi + 1, n, t.ntaps)};
             }
         }
@@ -539,98 +544,116 @@ __global__ __launch_bounds__(kBlock, OB == 4 ? 2 : 4) void fir_f64_mfma4_kernel(
     const bool g_swap = OB == 2 && ((tid >> 7) & 1) != 0;  // OB == 4: pairs with odd i (compile-time)
     if (tid < 2) bad_flag[tid] = 0;
 
+    // What the epilogue needs of a tile; kept from the moment the tile's first window is fetched.
+    struct Out {
+        double* yt;
+        long long left;
+        double post;
+        int odd;
+    };
+    auto out_of = [&](const M4Tile& t) __attribute__((always_inline)) { return Out{t.yrow + t.tile_start, n - t.tile_start, t.post, t.odd}; };
+
     // the first tile of this workgroup (positions k8, k8 + per_xcd, ... of the XCD's run)
-    M4Tile cur{};
     unsigned k = k8;
-    bool have = false;
-    for (; k < count && !(have = locate(k, cur)); k += per_xcd) {}
-    if (!have) return;  // the whole workgroup leaves together
-    if constexpr (BANK) stage_steps(cur.ntaps, total_steps, per_stage);
-    if (taps_stay) {
-        fetch_taps(cur, 0);
-        put_taps();
-    }
-    fetch(cur, 0, min(per_stage, max(total_steps, 1)));
-
-    for (unsigned parity = 0; have; parity ^= 1u) {
-        // the tile after this one: located here and for the loads of its first window, and again when it becomes `cur`
-        // (cheaper than carrying its description through the products)
-        bool have_next = false;
-        unsigned kn = k + per_xcd;
-        {
-            M4Tile nxt{};
-            for (; kn < count && !(have_next = locate(kn, nxt)); kn += per_xcd) {}
+    Out cur_out{}, nxt_out{};
+    {
+        M4Tile first_tile{};
+        bool have = false;
+        for (; k < count && !(have = locate(k, first_tile)); k += per_xcd) {}
+        if (!have) return;  // the whole workgroup leaves together
+        if constexpr (BANK) stage_steps(first_tile.ntaps, total_steps, per_stage);
+        if (taps_stay) {
+            fetch_taps(first_tile, 0);
+            put_taps();
         }
+        cur_out = out_of(first_tile);
+        fetch(first_tile, k, 0, min(per_stage, max(total_steps, 1)));
+    }
 
-        double acc[RB];
+    double acc[RB];
 #pragma unroll
-        for (int rb = 0; rb < RB; ++rb) acc[rb] = 0.0;
-
-        int e0 = 0;
-        do {  // windows of this tile (one unless the filter is longer than a window reaches; none of zero taps: one, idle)
-            const int steps = min(per_stage, max(total_steps, 1) - e0);
-            commit(cur, e0, steps);  // everybody is past the previous window's products (barriers below)
-            // start the loads of the window after this one
-            const int e_next = e0 + steps;
-            if (e_next < total_steps) {
-                fetch(cur, e_next, min(per_stage, total_steps - e_next));
-            } else if (have_next) {
-                M4Tile nxt{};
-                (void)locate(kn, nxt);
-                int next_total = total_steps, next_per = per_stage;
-                if constexpr (BANK) stage_steps(nxt.ntaps, next_total, next_per);
-                fetch(nxt, 0, min(next_per, max(next_total, 1)));
+    for (int rb = 0; rb < RB; ++rb) acc[rb] = 0.0;
+    int e0 = 0;
+    unsigned parity = 0;
+    // One pass per window: a tile has one unless its filter is longer than a window reaches.
+    for (bool more = true; more;) {
+        const int steps = fsteps;
+        commit();  // everybody is past the previous window's products (barriers below)
+        // start the loads of the window after this one: the next stage of this tile, or the next tile
+        const int e_next = e0 + steps;
+        const bool tile_done = e_next >= total_steps;
+        unsigned kn = k;
+        int next_total = total_steps, next_per = per_stage;
+        {
+            M4Tile t{};
+            bool have = false;
+            if (!tile_done) {
+                have = locate(k, t);
+            } else {
+                for (kn = k + per_xcd; kn < count && !(have = locate(kn, t)); kn += per_xcd) {}
+                if (have) {
+                    if constexpr (BANK) stage_steps(t.ntaps, next_total, next_per);
+                    nxt_out = out_of(t);
+                }
             }
-            __syncthreads();
+            more = have;
+            if (have) {
+                const int ne0 = tile_done ? 0 : e_next;
+                fetch(t, kn, ne0, min(next_per, max(next_total, 1) - ne0));
+            }
+        }
+        __syncthreads();
 
-            if (total_steps > 0) {
-                // V(s) = the four-sample vector at offset -4s from the lane's segment start: w_home[-4s], two doubles
-                // lower for every pad group crossed.  Row block rb uses V(el - rb) at step el.  w[] is a circular window
-                // over them, V(s) in slot s mod RB: a step runs its row blocks from the last to the first, so the slot the
-                // oldest vector leaves is refilled (for the next step's row block 0) right after its last use, a whole
-                // step ahead of its first.  Steps run in groups of RB: within a group every refill V(el + u + 1) lies in
-                // one pad group, so a group reads at constant distances from one pointer that moves by kPadStep per group.
-                double w[RB];
+        if (total_steps > 0) {
+            // V(s) = the four-sample vector at offset -4s from the lane's segment start: w_home[-4s], two doubles
+            // lower for every pad group crossed.  Row block rb uses V(el - rb) at step el.  w[] is a circular window
+            // over them, V(s) in slot s mod RB: a step runs its row blocks from the last to the first, so the slot the
+            // oldest vector leaves is refilled (for the next step's row block 0) right after its last use, a whole
+            // step ahead of its first.  Steps run in groups of RB: within a group every refill V(el + u + 1) lies in
+            // one pad group, so a group reads at constant distances from one pointer that moves by kPadStep per group.
+            double w[RB];
 #pragma unroll
-                for (int j = 1; j < RB; ++j) w[j] = w_home[4 * (RB - j)];
-                w[0] = w_home[0];
-                const double* wp = w_home - G::kPadStep;  // V(el + u + 1) = wp[kSeg - 4*(u + 1)] for the group at el
-                const double* ap = a_home;                // tap vector of step el + u = ap[4*u]
-                double a_now = ap[0];
-                int el = 0;
-                for (; el + RB <= steps; el += RB, wp -= G::kPadStep, ap += 4 * RB) {
+            for (int j = 1; j < RB; ++j) w[j] = w_home[4 * (RB - j)];
+            w[0] = w_home[0];
+            const double* wp = w_home - G::kPadStep;  // V(el + u + 1) = wp[kSeg - 4*(u + 1)] for the group at el
+            const double* ap = a_home;                // tap vector of step el + u = ap[4*u]
+            double a_now = ap[0];
+            int el = 0;
+            for (; el + RB <= steps; el += RB, wp -= G::kPadStep, ap += 4 * RB) {
 #pragma unroll
-                    for (int u = 0; u < RB; ++u) {
+                for (int u = 0; u < RB; ++u) {
+                    const double a = a_now;
+                    a_now = ap[4 * (u + 1)];  // the table has a spare step past the last
+#pragma unroll
+                    for (int rb = RB - 1; rb >= 0; --rb) {
+                        acc[rb] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, w[(u - rb + RB) % RB], acc[rb], 0, 0, 0);
+                        if (rb == RB - 1) w[(u + 1) % RB] = wp[G::kSeg - 4 * (u + 1)];  // at most one step past the window: in the image
+                    }
+                    __builtin_amdgcn_sched_barrier(0);  // keep every step's two LDS reads in their step (a step ahead of their use)
+                }
+            }
+            if (el < steps) {  // the window's last steps, fewer than RB of them (wave-uniform branches)
+                const int rem = steps - el;
+#pragma unroll
+                for (int u = 0; u < RB - 1; ++u) {
+                    if (u < rem) {
                         const double a = a_now;
-                        a_now = ap[4 * (u + 1)];  // the table has a spare step past the last
+                        a_now = ap[4 * (u + 1)];
 #pragma unroll
                         for (int rb = RB - 1; rb >= 0; --rb) {
                             acc[rb] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, w[(u - rb + RB) % RB], acc[rb], 0, 0, 0);
-                            if (rb == RB - 1) w[(u + 1) % RB] = wp[G::kSeg - 4 * (u + 1)];  // at most one step past the window: in the image
+                            if (rb == RB - 1) w[(u + 1) % RB] = wp[G::kSeg - 4 * (u + 1)];
                         }
-                        __builtin_amdgcn_sched_barrier(0);  // keep every step's two LDS reads in their step (a step ahead of their use)
-                    }
-                }
-                if (el < steps) {  // the window's last steps, fewer than RB of them (wave-uniform branches)
-                    const int rem = steps - el;
-#pragma unroll
-                    for (int u = 0; u < RB - 1; ++u) {
-                        if (u < rem) {
-                            const double a = a_now;
-                            a_now = ap[4 * (u + 1)];
-#pragma unroll
-                            for (int rb = RB - 1; rb >= 0; --rb) {
-                                acc[rb] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, w[(u - rb + RB) % RB], acc[rb], 0, 0, 0);
-                                if (rb == RB - 1) w[(u + 1) % RB] = wp[G::kSeg - 4 * (u + 1)];
-                            }
-                            __builtin_amdgcn_sched_barrier(0);
-                        }
+                        __builtin_amdgcn_sched_barrier(0);
                     }
                 }
             }
+        }
+        if (!tile_done) {
             e0 = e_next;
-            if (e0 < total_steps) __syncthreads();  // the image is rewritten for the next window
-        } while (e0 < total_steps);
+            __syncthreads();  // the image is rewritten for the next window
+            continue;
+        }
 
         // ---- accumulators -> second LDS buffer ----
         // The zero taps at the band's edges multiply real samples and the zero samples in front of a channel multiply
@@ -643,44 +666,46 @@ __global__ __launch_bounds__(kBlock, OB == 4 ? 2 : 4) void fir_f64_mfma4_kernel(
         for (int rb = 0; rb < RB; ++rb) {
             if (rb) probe += acc[rb];
             o_home[4 * rb] = acc[rb];
+            acc[rb] = 0.0;
         }
         if (not_finite(probe)) bad_flag[parity] = 1;
         __syncthreads();  // also: everybody is past this tile's products
         const bool bad = bad_flag[parity] != 0;  // workgroup-uniform
         if (tid == 0) bad_flag[parity ^ 1u] = 0;  // not written again before the next tile's barriers
+        parity ^= 1u;
 
-        double* __restrict__ yt = cur.yrow + cur.tile_start;
-        const long long left = n - cur.tile_start;
+        double* __restrict__ yt = cur_out.yt;
+        const long long left = cur_out.left;
         constexpr int kOutputs = BANK ? G::kBankStride : G::kTile;
         if (bad) {
             // one output at a time, every sample from memory again (rare and slow by design)
+            M4Tile t{};
+            (void)locate(k, t);
             double* outd = reinterpret_cast<double*>(outb);
-            const int extra = BANK ? 1 + cur.odd : 0;  // bank mode needs c one or two samples past the tile
+            const int extra = BANK ? 1 + t.odd : 0;  // bank mode needs c one or two samples past the tile
             __syncthreads();
             for (int o = tid; o < kOutputs + extra + 1; o += kBlock) {
                 double sum = 0.0;
-                for (int j = 0; j < cur.ntaps; ++j) {
-                    const long long g = cur.pos0 + o - j;
+                for (int j = 0; j < t.ntaps; ++j) {
+                    const long long g = t.pos0 + o - j;
                     if (g >= 0 && g < n)
-                        sum = __builtin_fma(cur.tapsc[j], cur.xc[g], sum);
-                    else if (g < 0 && cur.hc != nullptr && g >= -(long long)(cur.ntaps - 1))
-                        sum = __builtin_fma(cur.tapsc[j], cur.hc[(cur.ntaps - 1) + g], sum);
+                        sum = __builtin_fma(t.tapsc[j], t.xc[g], sum);
+                    else if (g < 0 && t.hc != nullptr && g >= -(long long)(t.ntaps - 1))
+                        sum = __builtin_fma(t.tapsc[j], t.hc[(t.ntaps - 1) + g], sum);
                 }
                 outd[o] = sum;
             }
             __syncthreads();
             for (int o = tid; o < kOutputs; o += kBlock) {
-                if (o < left) yt[o] = BANK ? (outd[o + cur.odd + 1] - outd[o + cur.odd]) * cur.post : outd[o];
+                if (o < left) yt[o] = BANK ? (outd[o + t.odd + 1] - outd[o + t.odd]) * t.post : outd[o];
             }
             __syncthreads();  // the buffer is free for the next tile
         } else {
-            constexpr int kPairStep = kBlock + (kBlock >> (G::kShift - 1));  // image distance of pairs kBlock apart
             auto out_pair = [&](int i) __attribute__((always_inline)) {  // outputs 2*pi, 2*pi + 1 of the tile, pi = tid + i*kBlock
                 const double2 v = g_home[i * kPairStep];
                 const bool swapped = OB == 4 ? (i & 1) != 0 : g_swap;
                 return swapped ? make_double2(v.y, v.x) : v;
             };
-            char* dst = reinterpret_cast<char*>(yt);  // wave-uniform
             const bool whole = !BANK && left >= G::kTile;
 #pragma unroll
             for (int i = 0; i < G::kTile / 2 / kBlock; ++i) {
@@ -696,26 +721,24 @@ __global__ __launch_bounds__(kBlock, OB == 4 ? 2 : 4) void fir_f64_mfma4_kernel(
                     } else {
                         c23 = o;  // the tile's last pair is never stored
                     }
-                    o = cur.odd ? make_double2((c23.x - o.y) * cur.post, (c23.y - c23.x) * cur.post)
-                                : make_double2((o.y - o.x) * cur.post, (c23.x - o.y) * cur.post);
+                    o = cur_out.odd ? make_double2((c23.x - o.y) * cur_out.post, (c23.y - c23.x) * cur_out.post)
+                                    : make_double2((o.y - o.x) * cur_out.post, (c23.x - o.y) * cur_out.post);
                     if (2 * pi >= G::kBankStride) continue;
                 }
-                char* p = dst + (size_t)i * kBlock * 16 + lane_bytes;
+                dvec2* dst = reinterpret_cast<dvec2*>(yt) + i * kBlock;  // wave-uniform
                 if (whole || 2 * pi + 1 < left) {
                     if constexpr (VEC2)
-                        stream_store(reinterpret_cast<dvec2*>(p), dvec2{o.x, o.y});
+                        stream_store(dst + (unsigned)tid, dvec2{o.x, o.y});
                     else
-                        reinterpret_cast<double*>(p)[0] = o.x, reinterpret_cast<double*>(p)[1] = o.y;
+                        yt[2 * pi] = o.x, yt[2 * pi + 1] = o.y;
                 } else if (2 * pi < left) {
-                    reinterpret_cast<double*>(p)[0] = o.x;
+                    yt[2 * pi] = o.x;
                 }
             }
         }
-        k = kn, have = have_next;
-        if (have) {
-            (void)locate(k, cur);
-            if constexpr (BANK) stage_steps(cur.ntaps, total_steps, per_stage);
-        }
+        k = kn, e0 = 0;
+        cur_out = nxt_out;
+        total_steps = next_total, per_stage = next_per;
     }
 }
 
