@@ -52,6 +52,12 @@ SIGNATURES = {
     "dspx_lfilter_f64_dev_noalloc": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
                                                C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
                                                C.c_size_t, C.c_size_t, C.c_uint, C.c_void_p]),
+    "dspx_fir_f32": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "dspx_fir_f32_from_f64": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "dspx_fir_f32_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p,
+                                   C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p]),
+    "dspx_fir_f32_from_f64_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                            C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p]),
     "dspx_fir_plan": (C.c_long, [C.c_size_t, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t]),
     "dspx_fir_f64_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
                                    C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_uint, C.c_void_p]),

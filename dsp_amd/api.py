@@ -70,6 +70,44 @@ def lfilter(b, x, exact: bool = False, mfma=None, out=None) -> np.ndarray:
     return y
 
 
+def lfilter_f32(b, x) -> np.ndarray:
+    """dsp::lfilter<float>(b, 1.0f, x) for 1-D host arrays.  float32 taps and samples: products in float
+    (dspx_fir_f32); anything else is taken as double: products in double, rounded to float, float sums
+    (dspx_fir_f32_from_f64, what the reference computes for containers of double)."""
+    b, x = np.asarray(b), np.asarray(x)
+    if b.dtype == np.float32 and x.dtype == np.float32:
+        b, x = np.ascontiguousarray(b), np.ascontiguousarray(x)
+        y = np.empty(x.size, dtype=np.float32)
+        check(lib().dspx_fir_f32(b.ctypes.data, b.size, x.ctypes.data, y.ctypes.data, x.size))
+        return y
+    b, x = _np_f64(b), _np_f64(x)
+    y = np.empty(x.size, dtype=np.float32)
+    check(lib().dspx_fir_f32_from_f64(b.ctypes.data, b.size, x.ctypes.data, y.ctypes.data, x.size))
+    return y
+
+
+def fir_f32_device(taps, x, out=None, hist=None):
+    """dspx_fir_f32_dev / dspx_fir_f32_from_f64_dev on torch CUDA tensors (float32 or float64 taps and x, float32 out)."""
+    import torch
+
+    assert x.is_cuda and taps.is_cuda and taps.dtype == x.dtype and x.dtype in (torch.float32, torch.float64)
+    x2 = x.reshape(1, -1) if x.dim() == 1 else x
+    assert x2.dim() == 2 and x2.stride(1) == 1
+    if out is None:
+        out = torch.empty(x2.shape, dtype=torch.float32, device=x.device)
+    o2 = out.reshape(1, -1) if out.dim() == 1 else out
+    assert o2.shape == x2.shape and o2.stride(1) == 1 and o2.dtype == torch.float32
+    hptr, hstride = None, 0
+    if hist is not None:
+        h2 = hist.reshape(1, -1) if hist.dim() == 1 else hist
+        assert h2.dtype == x.dtype and h2.shape == (x2.shape[0], max(taps.numel() - 1, 0)) and (h2.stride(1) == 1 or h2.shape[1] <= 1)
+        hptr, hstride = h2.data_ptr(), h2.stride(0)
+    fn = lib().dspx_fir_f32_dev if x.dtype == torch.float32 else lib().dspx_fir_f32_from_f64_dev
+    check(fn(taps.data_ptr(), taps.numel(), x2.data_ptr(), x2.stride(0), hptr, hstride, o2.data_ptr(), o2.stride(0),
+             x2.shape[0], x2.shape[1], _stream_ptr()))
+    return out.reshape(x.shape) if out.dim() != x.dim() else out
+
+
 def lfilter_iir(b, a, x, exact: bool = False, mfma=None, ngpus=None) -> np.ndarray:
     """dsp::lfilter(b, a, x) with a recursive part (dsp.hpp:342-371) for host arrays: 1-D x, or 2-D
     (channels, samples).  a[0] is never read.  ngpus: shard the channels over that many devices (0 = all)."""

@@ -12,6 +12,7 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <type_traits>
 #include <vector>
 
 #include "dsp.hpp"
@@ -611,6 +612,68 @@ int host_path_body(const double* taps, size_t ntaps, const double* hist0, const 
 }
 
 
+// lfilter<float>: TIN is the type the products are formed in (float or double containers), the result is float.
+template <typename TIN>
+int narrow_dev(const TIN* d_taps, size_t ntaps, const TIN* d_x, size_t x_stride, const TIN* d_hist, size_t hist_stride,
+               float* d_y, size_t y_stride, size_t nchan, size_t n, hipStream_t stream) {
+    if (ntaps > 0x7fffffffull) return fail(DSPX_ERR_INVALID, "ntaps too large: %zu", ntaps);
+    if (ntaps && !d_taps) return fail(DSPX_ERR_INVALID, "taps is NULL");
+    if (nchan && n && (!d_x || !d_y)) return fail(DSPX_ERR_INVALID, "x or y is NULL");
+    if (nchan == 0 || n == 0) return DSPX_OK;
+    if (nchan > 1 && (x_stride < n || y_stride < n))
+        return fail(DSPX_ERR_INVALID, "channel stride smaller than n (%zu): x %zu, y %zu", n, x_stride, y_stride);
+    if (d_hist && nchan > 1 && ntaps > 1 && hist_stride < ntaps - 1)
+        return fail(DSPX_ERR_INVALID, "hist_stride (%zu) < ntaps-1", hist_stride);
+    if (ranges_overlap(d_x, ((nchan - 1) * x_stride + n) * sizeof(TIN), d_y, ((nchan - 1) * y_stride + n) * sizeof(float)))
+        return fail(DSPX_ERR_INVALID, "d_x and d_y overlap");
+    const size_t tile = (size_t)dspx::fir_tile(), tiles_per_chan = (n + tile - 1) / tile;
+    if (tiles_per_chan > kMaxGrid) return fail(DSPX_ERR_INVALID, "n too large for one launch: %zu", n);
+    const size_t chans_per_launch = std::max<size_t>(1, kMaxGrid / tiles_per_chan);
+    for (size_t c0 = 0; c0 < nchan; c0 += chans_per_launch) {
+        const size_t nc = std::min(chans_per_launch, nchan - c0);
+        dspx::FirShape s{};
+        s.x_stride = x_stride, s.hist_stride = hist_stride, s.y_stride = y_stride;
+        s.n = (long long)n;
+        s.total_tiles = (unsigned)(nc * tiles_per_chan);
+        s.tiles_per_chan = (unsigned)tiles_per_chan;
+        s.ntaps = (int)ntaps;
+        const TIN* h = d_hist ? d_hist + c0 * hist_stride : nullptr;
+        if constexpr (std::is_same_v<TIN, float>)
+            DSPX_HIP(dspx::launch_fir_f32(d_taps, d_x + c0 * x_stride, h, d_y + c0 * y_stride, s, stream));
+        else
+            DSPX_HIP(dspx::launch_fir_f32_from_f64(d_taps, d_x + c0 * x_stride, h, d_y + c0 * y_stride, s, stream));
+    }
+    return DSPX_OK;
+}
+
+// Host pointers, one channel: plain allocate / copy / filter / copy back (no staging pipeline: this path is functional).
+template <typename TIN> int narrow_host(const TIN* taps, size_t ntaps, const TIN* x, float* y, size_t n) {
+    if (ntaps && !taps) return fail(DSPX_ERR_INVALID, "taps is NULL");
+    if (n && (!x || !y)) return fail(DSPX_ERR_INVALID, "x or y is NULL");
+    if (n == 0) return DSPX_OK;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(DSPX_ERR_NO_DEVICE, "no HIP device");
+    TIN *d_taps = nullptr, *d_x = nullptr;
+    float* d_y = nullptr;
+    auto body = [&]() -> int {
+        DSPX_HIP(hipMalloc((void**)&d_taps, std::max<size_t>(ntaps, 1) * sizeof(TIN)));
+        DSPX_HIP(hipMalloc((void**)&d_x, n * sizeof(TIN)));
+        DSPX_HIP(hipMalloc((void**)&d_y, n * sizeof(float)));
+        if (ntaps) DSPX_HIP(hipMemcpy(d_taps, taps, ntaps * sizeof(TIN), hipMemcpyHostToDevice));
+        DSPX_HIP(hipMemcpy(d_x, x, n * sizeof(TIN), hipMemcpyHostToDevice));
+        if (int rc = narrow_dev<TIN>(d_taps, ntaps, d_x, n, nullptr, 0, d_y, n, 1, n, nullptr)) return rc;
+        DSPX_HIP(hipMemcpy(y, d_y, n * sizeof(float), hipMemcpyDeviceToHost));
+        return DSPX_OK;
+    };
+    const int rc = body();
+    const std::string keep = g_last_error;
+    if (d_taps) (void)hipFree(d_taps);
+    if (d_x) (void)hipFree(d_x);
+    if (d_y) (void)hipFree(d_y);
+    if (rc != DSPX_OK) g_last_error = keep;
+    return rc;
+}
+
 // The host-pointer entry points: no C++ exception (allocation, thread creation) crosses the C ABI.
 int host_path(const double* taps, size_t ntaps, const double* hist0, const double* x, double* y, size_t nchan, size_t n,
               size_t stride, int ngpus, unsigned flags, const Tail& tail = Tail{}) {
@@ -869,6 +932,27 @@ int dspx_lfilter_f64_dev_noalloc(const double* d_b, size_t nb, const double* a, 
                        n, work, kStaticScratchBytes,
                        "the library's static scratch (DSPX_NOALLOC_SCRATCH_BYTES); use dspx_lfilter_f64_dev with a workspace",
                        flags, stream);
+}
+
+int dspx_fir_f32(const float* taps, size_t ntaps, const float* x, float* y, size_t n) {
+    return dspx::guarded([&] { return narrow_host<float>(taps, ntaps, x, y, n); });
+}
+
+int dspx_fir_f32_from_f64(const double* taps, size_t ntaps, const double* x, float* y, size_t n) {
+    return dspx::guarded([&] { return narrow_host<double>(taps, ntaps, x, y, n); });
+}
+
+int dspx_fir_f32_dev(const float* d_taps, size_t ntaps, const float* d_x, size_t x_stride, const float* d_hist,
+                     size_t hist_stride, float* d_y, size_t y_stride, size_t nchan, size_t n, void* stream) {
+    return narrow_dev<float>(d_taps, ntaps, d_x, x_stride, d_hist, hist_stride, d_y, y_stride, nchan, n,
+                             static_cast<hipStream_t>(stream));
+}
+
+int dspx_fir_f32_from_f64_dev(const double* d_taps, size_t ntaps, const double* d_x, size_t x_stride,
+                              const double* d_hist, size_t hist_stride, float* d_y, size_t y_stride, size_t nchan,
+                              size_t n, void* stream) {
+    return narrow_dev<double>(d_taps, ntaps, d_x, x_stride, d_hist, hist_stride, d_y, y_stride, nchan, n,
+                              static_cast<hipStream_t>(stream));
 }
 
 long dspx_fir_plan(size_t nchan, size_t n, int ngpus, dspx_piece* out, size_t cap) {

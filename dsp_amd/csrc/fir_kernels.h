@@ -54,6 +54,12 @@ hipError_t launch_fir_mfma_bank_f64(const double* taps, const BankRow* bank, con
 // divider divides by the run length); the other strides and ntaps are unused.
 hipError_t launch_fir_bank_f64(const double* taps, const BankRow* bank, const double* x, double* y,
                                const FirShape& shape, bool exact, bool vec2, hipStream_t stream);
+// lfilter<float>: float sums of products formed in float (containers of float) or in double (containers of double),
+// bit-identical to the reference loop; tiles are fir_tile() outputs, one workgroup each.
+hipError_t launch_fir_f32(const float* taps, const float* x, const float* hist, float* y, const FirShape& shape,
+                          hipStream_t stream);
+hipError_t launch_fir_f32_from_f64(const double* taps, const double* x, const double* hist, float* y,
+                                   const FirShape& shape, hipStream_t stream);
 hipError_t launch_fill_splitmix(double* x, unsigned long long n, unsigned long long seed, unsigned long long offset,
                                 hipStream_t stream);
 hipError_t launch_checksum(const double* y, unsigned long long n, unsigned long long offset, unsigned long long* out,

@@ -742,6 +742,68 @@ __global__ __launch_bounds__(kBlock, OB == 4 ? 2 : 4) void fir_f64_mfma4_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// lfilter<float> (reference dsp.hpp:361-364 with T = float): the sum is a float, and every product is formed in the
+// type the operands promote to -- double for containers of double, float for containers of float -- converted to
+// float and added, taps ascending.  TIN is that operand type.  Separately rounded operations in exactly the
+// reference's order, so the results are bit-identical to the reference loop; a product with a sample that does not
+// exist (before the start of a channel without history) is never formed.  A functional path for the reference's
+// single-precision instantiation, not a tuned one: one workgroup per tile of 2048 outputs, thread t owns outputs
+// t, t + 256, ..., taps and samples through LDS in chunks of 256 taps.
+constexpr int kNarrowTaps = 256;
+template <typename TIN>
+__global__ __launch_bounds__(kBlock) void fir_f32_kernel(const TIN* __restrict__ taps, const TIN* __restrict__ x,
+                                                          const TIN* __restrict__ hist, float* __restrict__ y,
+                                                          FirShape s) {
+    __shared__ TIN xs[kNarrowTaps - 1 + kTile];
+    __shared__ TIN tapl[kNarrowTaps];
+    const int tid = threadIdx.x;
+    const unsigned chan = blockIdx.x / s.tiles_per_chan, tile = blockIdx.x - chan * s.tiles_per_chan;
+    const long long n = s.n, tile_start = (long long)tile * kTile;
+    const int ntaps = s.ntaps;
+    const TIN* __restrict__ xc = x + (unsigned long long)chan * s.x_stride;
+    const TIN* __restrict__ hc = hist ? hist + (unsigned long long)chan * s.hist_stride : nullptr;
+    float acc[kR];
+    long long jmax[kR];  // output r adds taps j < jmax[r]: all of them, or as many as there are samples behind it
+#pragma unroll
+    for (int r = 0; r < kR; ++r) {
+        acc[r] = 0.0f;
+        const long long i = tile_start + tid + r * kBlock;
+        jmax[r] = hc ? (long long)ntaps : min((long long)ntaps, i + 1);
+    }
+    for (int j0 = 0; j0 < ntaps; j0 += kNarrowTaps) {
+        const int S = min(kNarrowTaps, ntaps - j0);
+        if (j0 > 0) __syncthreads();
+        if (tid < S) tapl[tid] = taps[j0 + tid];
+        // slot q <- sample tile_start - j0 - (kNarrowTaps - 1) + q; tap j0 + jj of output o reads slot kNarrowTaps - 1 + o - jj
+        for (int q = tid; q < kNarrowTaps - 1 + kTile; q += kBlock) {
+            const long long g = tile_start - j0 - (kNarrowTaps - 1) + q;
+            TIN v = 0;
+            if (g >= 0) {
+                if (g < n) v = xc[g];
+            } else if (hc != nullptr && g >= -(long long)(ntaps - 1)) {
+                v = hc[(ntaps - 1) + g];
+            }
+            xs[q] = v;
+        }
+        __syncthreads();
+        for (int jj = 0; jj < S; ++jj) {
+            const TIN b = tapl[jj];
+#pragma unroll
+            for (int r = 0; r < kR; ++r) {
+#pragma clang fp contract(off)
+                const float term = static_cast<float>(b * xs[kNarrowTaps - 1 + tid + r * kBlock - jj]);
+                if (j0 + jj < jmax[r]) acc[r] = acc[r] + term;
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < kR; ++r) {
+        const long long i = tile_start + tid + r * kBlock;
+        if (i < n) y[(unsigned long long)chan * s.y_stride + i] = acc[r];
+    }
+}
+
 // SplitMix64 finaliser.
 __device__ __forceinline__ unsigned long long mix64(unsigned long long z) {
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
@@ -861,6 +923,23 @@ hipError_t launch_fir_bank_f64(const double* taps, const BankRow* bank, const do
             hipLaunchKernelGGL((fir_f64_kernel<false, false, true>), grid, block, 0, stream, taps, x, none, y, bank, shape);
     }
     return hipGetLastError();
+}
+
+template <typename TIN>
+static hipError_t launch_fir_f32_any(const TIN* taps, const TIN* x, const TIN* hist, float* y, const FirShape& shape,
+                                     hipStream_t stream) {
+    if (shape.total_tiles == 0) return hipSuccess;
+    if (!grid_fits(shape.total_tiles)) return hipErrorInvalidConfiguration;
+    hipLaunchKernelGGL(fir_f32_kernel<TIN>, dim3(shape.total_tiles), dim3(kBlock), 0, stream, taps, x, hist, y, shape);
+    return hipGetLastError();
+}
+hipError_t launch_fir_f32(const float* taps, const float* x, const float* hist, float* y, const FirShape& shape,
+                          hipStream_t stream) {
+    return launch_fir_f32_any<float>(taps, x, hist, y, shape, stream);
+}
+hipError_t launch_fir_f32_from_f64(const double* taps, const double* x, const double* hist, float* y,
+                                   const FirShape& shape, hipStream_t stream) {
+    return launch_fir_f32_any<double>(taps, x, hist, y, shape, stream);
 }
 
 hipError_t launch_fill_splitmix(double* x, unsigned long long n, unsigned long long seed, unsigned long long offset,

@@ -17,8 +17,9 @@
 // reference loop (dsp.hpp:366-368) on the GPU as well.
 // There is no CPU filtering path in this header: a failing GPU call throws
 // std::runtime_error, and inputs the GPU path does not cover are rejected
-//   - at compile time when T is not double, or when the reference would form the products
-//     numerators * x in a type other than double (e.g. float taps over float samples),
+//   - at compile time when T is neither double nor float, or when T is double and the reference
+//     would form the products numerators * x in a type other than double (lfilter<float> sums in
+//     float, with products in float or double as the reference forms them, bit-identically),
 //   - with std::invalid_argument when the denominator has more than nine
 //     coefficients.
 //
@@ -95,10 +96,13 @@ concept iterable_of = requires(const C& c) {
     c.end();
 } && std::is_nothrow_convertible_v<typename C::value_type, T>;
 
-template <typename C>
-concept contiguous_doubles = requires(const C& c) {
-    { std::data(c) } -> std::convertible_to<const double*>;
+template <typename C, typename S>
+concept contiguous_of = requires(const C& c) {
+    { std::data(c) } -> std::convertible_to<const S*>;
 } && std::contiguous_iterator<decltype(std::begin(std::declval<const C&>()))>;
+
+template <typename C>
+concept contiguous_doubles = contiguous_of<C, double>;
 
 }  // namespace traits
 
@@ -187,27 +191,28 @@ template <typename T = double> struct lfilter_ctx_t { std::vector<T> result; };
 
 namespace detail {
 
-// Contiguous view of a container as doubles; copies (converting each element) only when the
-// container is not a contiguous array of double (e.g. std::deque<double>, std::vector<float>).
-template <typename C> class double_view {
+// Contiguous view of a container as elements of S; copies (converting each element) only when the
+// container is not a contiguous array of S (e.g. std::deque<double>, std::vector<float> viewed as double).
+template <typename S, typename C> class scalar_view {
   public:
-    explicit double_view(const C& c) : size_(c.size()) {
-        if constexpr (contiguous_doubles<C>) {
+    explicit scalar_view(const C& c) : size_(c.size()) {
+        if constexpr (contiguous_of<C, S>) {
             data_ = std::data(c);
         } else {
             copy_.resize(size_);
-            for (std::size_t i = 0; i < size_; ++i) copy_[i] = c[i];
+            for (std::size_t i = 0; i < size_; ++i) copy_[i] = static_cast<S>(c[i]);
             data_ = copy_.data();
         }
     }
-    const double* data() const { return data_; }
+    const S* data() const { return data_; }
     std::size_t size() const { return size_; }
 
   private:
-    std::vector<double> copy_;
-    const double* data_ = nullptr;
+    std::vector<S> copy_;
+    const S* data_ = nullptr;
     std::size_t size_;
 };
+template <typename C> using double_view = scalar_view<double, C>;
 
 }  // namespace detail
 
@@ -219,29 +224,45 @@ template <typename T = double, typename Container_1, typename Container_2, typen
 void lfilter(lfilter_ctx_t<T>& ctx, const Container_1& numerators, const Container_2& denominators,
              const Container_3& x) {
     // The reference multiplies numerators[j] * x[i-j] and denominators[j] * y[i-j] in the type the operands
-    // promote to and only then converts to T (dsp.hpp:363, 367).  Whenever those products are formed in double
-    // (at least one of numerators / x holds double, nothing holds long double), converting the other operand to
-    // double first -- which is all that happens to such containers here -- gives the same values.
+    // promote to and only then converts to T (dsp.hpp:363, 367).  Converting the narrower operand to that type
+    // first -- which is all that happens to the containers here -- gives the same values.
     using V1 = typename Container_1::value_type;
     using V2 = typename Container_2::value_type;
     using V3 = typename Container_3::value_type;
-    static_assert(std::is_same_v<T, double> && std::is_same_v<decltype(std::declval<V1>() * std::declval<V3>()), double> &&
-                    std::is_same_v<decltype(std::declval<V2>() * std::declval<double>()), double>,
-                  "dsp::lfilter (MI355X): T must be double and the products numerators * x and denominators * y "
-                  "must be formed in double (e.g. double taps over float or integer samples)");
+    using product_t = decltype(std::declval<V1>() * std::declval<V3>());
+    static_assert(std::is_same_v<T, double> || std::is_same_v<T, float>, "dsp::lfilter (MI355X): T must be double or float");
     const std::size_t n = x.size();
     if (ctx.result.size() != n) [[unlikely]] ctx.result.resize(n);
     if (n == 0) return;
-    const detail::double_view<Container_1> b(numerators);
-    const detail::double_view<Container_3> in(x);
     int rc;
-    if (denominators.size() > 1) {  // the recursive tail, dsp.hpp:366-368
-        const detail::double_view<Container_2> a(denominators);
-        rc = dspx_lfilter_f64(b.data(), b.size(), a.data(), a.size(), in.data(), ctx.result.data(), 1, n, n,
-                              DSPX_FIR_FMA);
-        if (rc == DSPX_ERR_INVALID) throw std::invalid_argument(std::string("dsp::lfilter (MI355X): ") + dspx_last_error());
+    if constexpr (std::is_same_v<T, float>) {
+        // single precision (dsp.hpp:361-364 with T = float): float sums of products formed in float or in double
+        static_assert(std::is_same_v<product_t, float> || std::is_same_v<product_t, double>,
+                      "dsp::lfilter<float> (MI355X): the products numerators * x must be formed in float or double");
+        if (denominators.size() > 1)
+            throw std::invalid_argument("dsp::lfilter<float> (MI355X): a recursive part is implemented for T = double only");
+        const detail::scalar_view<product_t, Container_1> b(numerators);
+        const detail::scalar_view<product_t, Container_3> in(x);
+        if constexpr (std::is_same_v<product_t, float>)
+            rc = dspx_fir_f32(b.data(), b.size(), in.data(), ctx.result.data(), n);
+        else
+            rc = dspx_fir_f32_from_f64(b.data(), b.size(), in.data(), ctx.result.data(), n);
     } else {
-        rc = dspx_fir_f64(b.data(), b.size(), in.data(), ctx.result.data(), n, DSPX_FIR_FMA);
+        static_assert(std::is_same_v<product_t, double> &&
+                        std::is_same_v<decltype(std::declval<V2>() * std::declval<double>()), double>,
+                      "dsp::lfilter<double> (MI355X): the products numerators * x and denominators * y must be formed "
+                      "in double (e.g. double taps over float or integer samples)");
+        const detail::double_view<Container_1> b(numerators);
+        const detail::double_view<Container_3> in(x);
+        if (denominators.size() > 1) {  // the recursive tail, dsp.hpp:366-368
+            const detail::double_view<Container_2> a(denominators);
+            rc = dspx_lfilter_f64(b.data(), b.size(), a.data(), a.size(), in.data(), ctx.result.data(), 1, n, n,
+                                  DSPX_FIR_FMA);
+            if (rc == DSPX_ERR_INVALID)
+                throw std::invalid_argument(std::string("dsp::lfilter (MI355X): ") + dspx_last_error());
+        } else {
+            rc = dspx_fir_f64(b.data(), b.size(), in.data(), ctx.result.data(), n, DSPX_FIR_FMA);
+        }
     }
     if (rc != DSPX_OK)
         throw std::runtime_error(std::string("dsp::lfilter (MI355X): ") + dspx_status_string(rc) + ": " +

@@ -180,6 +180,22 @@ DSPX_API int dspx_fir_f64_dev(const double* d_taps, size_t ntaps, const double* 
                      size_t hist_stride, double* d_y, size_t y_stride, size_t nchan, size_t n, unsigned flags,
                      void* stream);
 
+/* ---- single precision: lfilter<float>                                                dsp.hpp:333-396 with T = float
+ * The reference sums in float and forms every product numerators[j] * x[i-j] in the type its operands promote to
+ * (dsp.hpp:363): in float for containers of float (dspx_fir_f32), in double for containers of double
+ * (dspx_fir_f32_from_f64 -- the form the reference's own test uses, dsp.hpp:1590-1597: double taps and samples, float
+ * result).  Multiply, conversion and add are rounded separately, taps ascending: bit-identical to the reference loop
+ * compiled without contraction.  Functional, not tuned (the tuned path is double).  Host pointers, current device;
+ * the _dev forms take device pointers, nchan channels (channel c at + c*stride), an optional history of ntaps-1
+ * samples per channel as dspx_fir_f64_dev, and a stream. */
+DSPX_API int dspx_fir_f32(const float* taps, size_t ntaps, const float* x, float* y, size_t n);
+DSPX_API int dspx_fir_f32_from_f64(const double* taps, size_t ntaps, const double* x, float* y, size_t n);
+DSPX_API int dspx_fir_f32_dev(const float* d_taps, size_t ntaps, const float* d_x, size_t x_stride, const float* d_hist,
+                              size_t hist_stride, float* d_y, size_t y_stride, size_t nchan, size_t n, void* stream);
+DSPX_API int dspx_fir_f32_from_f64_dev(const double* d_taps, size_t ntaps, const double* d_x, size_t x_stride,
+                                       const double* d_hist, size_t hist_stride, float* d_y, size_t y_stride,
+                                       size_t nchan, size_t n, void* stream);
+
 /* ---- wavelet bank on the FIR kernel ---------------------------------------------------
  * integrate_wavelet<double>(MORLET, precision, lower, upper)   dsp.hpp:934-985   (host arithmetic)
  * psi and x each hold 2^precision doubles. */

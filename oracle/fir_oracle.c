@@ -161,6 +161,18 @@ void oracle_lfilter_f32(const float* b, size_t nb, const float* x, size_t n, flo
     }
 }
 
+/* lfilter<float> over containers of double (what the reference's own test_lfilter calls, dsp.hpp:1590-1597):
+ * the product is formed in double, converted to float, and added to a float sum (dsp.hpp:361-364 with T = float). */
+void oracle_lfilter_f32_from_f64(const double* b, size_t nb, const double* x, size_t n, float* y) {
+    for (size_t i = 0; i < n; ++i) {
+        const size_t ip1 = i + 1;
+        const size_t nb_end = nb < ip1 ? nb : ip1;
+        float sum = 0.0f;
+        for (size_t j = 0; j < nb_end; ++j) sum += (float)(b[j] * x[i - j]);
+        y[i] = sum;
+    }
+}
+
 /* Deterministic synthetic input shared by CPU and GPU:
  * x[idx] = ((mix(seed + (idx+1)*GAMMA) >> 11) * 2^-52) - 1.0, uniform in [-1, 1),
  * where mix() is the SplitMix64 finaliser.  Every value is exactly representable. */

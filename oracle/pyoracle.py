@@ -53,6 +53,8 @@ class Oracle:
         L.oracle_fir_f64_hist.argtypes = [_f64p, C.c_size_t, C.c_void_p, _f64p, C.c_size_t, _f64p]
         L.oracle_lfilter_f32.restype = None
         L.oracle_lfilter_f32.argtypes = [_f32p, C.c_size_t, _f32p, C.c_size_t, _f32p]
+        L.oracle_lfilter_f32_from_f64.restype = None
+        L.oracle_lfilter_f32_from_f64.argtypes = [_f64p, C.c_size_t, _f64p, C.c_size_t, _f32p]
         L.oracle_fill_splitmix_f64.restype = None
         L.oracle_fill_splitmix_f64.argtypes = [_f64p, C.c_size_t, C.c_uint64, C.c_uint64]
         L.oracle_checksum_f64.restype = C.c_uint64
@@ -113,6 +115,14 @@ class Oracle:
                                   y if y.size else np.zeros(1, np.float32))
         return y
 
+    def lfilter_f32_from_f64(self, b, x) -> np.ndarray:
+        """lfilter<float> over double containers: double products, rounded to float, float sums."""
+        b, x = _f64(b), _f64(x)
+        y = np.empty(x.size, dtype=np.float32)
+        self.L.oracle_lfilter_f32_from_f64(b if b.size else np.zeros(1), b.size, x if x.size else np.zeros(1), x.size,
+                                           y if y.size else np.zeros(1, np.float32))
+        return y
+
     def fill_splitmix(self, n: int, seed: int = SEED, offset: int = 0) -> np.ndarray:
         x = np.empty(n, dtype=np.float64)
         if n:
@@ -162,6 +172,7 @@ class Reference:
         L.ref_lfilter.argtypes = [_f64p, C.c_size_t, _f64p, C.c_size_t, _f64p, C.c_size_t, _f64p]
         L.ref_lfilter_scalar_den.argtypes = [_f64p, C.c_size_t, C.c_double, _f64p, C.c_size_t, _f64p]
         L.ref_lfilter_f32.argtypes = [_f32p, C.c_size_t, _f32p, C.c_size_t, _f32p]
+        L.ref_lfilter_f32_from_f64.argtypes = [_f64p, C.c_size_t, _f64p, C.c_size_t, _f32p]
         L.ref_integrate_wavelet.argtypes = [C.c_size_t, _f64p, _f64p]
         L.ref_cwt.argtypes = [_f64p, C.c_size_t, _f64p, C.c_size_t, _f64p, _f64p, C.c_size_t, _f64p]
         self.L = L
@@ -212,6 +223,13 @@ class Reference:
         x = np.ascontiguousarray(x, dtype=np.float32)
         y = np.empty(max(x.size, 1), dtype=np.float32)
         rc = self.L.ref_lfilter_f32(b, b.size, x, x.size, y)
+        assert rc == 0
+        return y[: x.size]
+
+    def lfilter_f32_from_f64(self, b, x):
+        b, x = _f64(b), _f64(x)
+        y = np.empty(max(x.size, 1), dtype=np.float32)
+        rc = self.L.ref_lfilter_f32_from_f64(b if b.size else np.zeros(1), b.size, x if x.size else np.zeros(1), x.size, y)
         assert rc == 0
         return y[: x.size]
 

@@ -78,6 +78,14 @@ int ref_lfilter_f32(const float* b, size_t nb, const float* x, size_t n, float* 
     });
 }
 
+int ref_lfilter_f32_from_f64(const double* b, size_t nb, const double* x, size_t n, float* y) {
+    return guarded([&] {
+        std::vector<double> vb(b, b + nb), vx(x, x + n);
+        const auto r = dsp::lfilter<float>(vb, 1.0f, vx);
+        if (!r.empty()) std::memcpy(y, r.data(), r.size() * sizeof(float));
+    });
+}
+
 int ref_integrate_wavelet(size_t precision, double* psi, double* x) {
     return guarded([&] {
         auto [p, t] = dsp::integrate_wavelet<double>(dsp::cwt_wavelet_t::MORLET, precision);

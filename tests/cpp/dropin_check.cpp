@@ -70,6 +70,10 @@ int main(int argc, char** argv) {
         auto w = firwin<double>(std::strtoul(argv[2], nullptr, 10), std::strtod(argv[3], nullptr));
         auto r = lfilter<double>(w, 1.0, x);
         dump("y", r);
+        // the single-precision instantiation of the reference's test_lfilter (dsp.hpp:1590-1597): float result over the
+        // same double taps and data
+        auto rf = lfilter<float>(w, 1.0, x);
+        dump("yf", std::vector<double>(rf.begin(), rf.end()));
         return 0;
     }
     if (mode == "wavelet" && argc == 3) {
@@ -153,6 +157,27 @@ int main(int argc, char** argv) {
             std::vector<float> wf(w.begin(), w.end());
             std::vector<double> wf_as_double(wf.begin(), wf.end());
             CHECK(lfilter<double>(wf, 1.0, x) == lfilter<double>(wf_as_double, 1.0, x));
+        }
+        // lfilter<float>: float sums; products in double for containers of double, in float for containers of float,
+        // each compared bit for bit with the reference's loop written out here (dsp.hpp:356-365)
+        {
+            std::vector<float> wf(w.begin(), w.end()), xf(x.begin(), x.end());
+            std::vector<float> want_dd(x.size()), want_ff(x.size());
+            for (size_t i = 0; i < x.size(); ++i) {
+                float sum_dd = 0.0f, sum_ff = 0.0f;
+                for (size_t j = 0; j < std::min(w.size(), i + 1); ++j) {
+                    sum_dd += static_cast<float>(w[j] * x[i - j]);
+                    sum_ff += static_cast<float>(wf[j] * xf[i - j]);
+                }
+                want_dd[i] = sum_dd, want_ff[i] = sum_ff;
+            }
+            CHECK(lfilter<float>(w, 1.0f, x) == want_dd);
+            CHECK(lfilter<float>(wf, 1.0f, xf) == want_ff);
+            lfilter_ctx_t<float> fctx;
+            lfilter<float>(fctx, wf, std::vector<float>{1.0f}, xf);
+            CHECK(fctx.result == want_ff);
+            CHECK(lfilter<float>(wf, 1.0f, std::vector<float>{}).empty());
+            CHECK(throws<std::invalid_argument>([&] { lfilter<float>(wf, std::vector<float>{1.0f, -0.5f}, xf); }));
         }
         // empty input -> empty output, empty numerators -> zeros
         CHECK(lfilter<double>(w, 1.0, std::vector<double>{}).empty());

@@ -162,8 +162,12 @@ def test_cpp_reference_test_lfilter(dropin, literals):
     t = literals["lfilter"]
     inp = "\n".join(float(v).hex() for v in t["data"])
     r = subprocess.run([dropin, "filter", "100", "0.5"], input=inp, capture_output=True, text=True, check=True)
-    y = np.array([float.fromhex(v) for v in r.stdout.split()[2:]])
-    assert y.size == 100 and np.max(np.abs(y - np.array(t["expected"]))) < t["tol"]  # dsp.hpp:1583-1588
+    toks = r.stdout.split()
+    assert toks[0] == "y" and toks[1] == "100" and toks[102] == "yf" and toks[103] == "100"
+    y = np.array([float.fromhex(v) for v in toks[2:102]])
+    assert np.max(np.abs(y - np.array(t["expected"]))) < t["tol"]  # dsp.hpp:1583-1588
+    yf = np.array([float.fromhex(v) for v in toks[104:204]])       # lfilter<float>, dsp.hpp:1590-1597
+    assert np.max(np.abs(yf - np.array(t["expected"]))) < t["tol_f32"]
 
 
 @pytest.mark.gpu

@@ -321,3 +321,49 @@ def test_streaming_chunks_reproduce_one_call(dsp, oracle, ntaps):
     assert np.array_equal(bits(np.concatenate(out, axis=1)), bits(ref))
     if ntaps > 1:
         assert np.array_equal(bits(hist), bits(x[:, n - (ntaps - 1):]))
+
+
+@pytest.mark.parametrize("ntaps", [1, 7, 100, 255, 256, 257, 700])
+def test_single_precision_is_bit_identical(dsp, oracle, ntaps):
+    """dsp::lfilter<float> (dspx_fir_f32, dspx_fir_f32_from_f64): float sums of products formed in float (containers
+    of float) or in double (containers of double), bit for bit the reference loop; ragged lengths, several channels
+    and a history through the device entry points."""
+    import torch
+
+    rng = np.random.default_rng(ntaps)
+    b = rng.standard_normal(ntaps)
+    for n in (1, 2, 255, 2047, 2048, 2049, 5000):
+        x = rng.standard_normal(n)
+        want = oracle.lfilter_f32_from_f64(b, x)
+        assert np.array_equal(dsp.lfilter_f32(b, x).view(np.uint32), want.view(np.uint32)), n
+        b32, x32 = b.astype(np.float32), x.astype(np.float32)
+        want = oracle.lfilter_f32(b32, x32)
+        assert np.array_equal(dsp.lfilter_f32(b32, x32).view(np.uint32), want.view(np.uint32)), n
+    # device entry points: 3 channels, and a second half that continues the first through a history
+    n, cut = 6001, 2500
+    x = rng.standard_normal((3, n))
+    for dt, orc in ((torch.float64, oracle.lfilter_f32_from_f64), (torch.float32, oracle.lfilter_f32)):
+        xh = x.astype(np.float32) if dt == torch.float32 else x
+        bh = b.astype(np.float32) if dt == torch.float32 else b
+        want = np.stack([orc(bh, xh[c]) for c in range(3)])
+        xd, bd = torch.from_numpy(xh).cuda(), torch.from_numpy(bh).cuda()
+        got = dsp.fir_f32_device(bd, xd)
+        assert np.array_equal(got.cpu().numpy().view(np.uint32), want.view(np.uint32))
+        if ntaps > 1 and cut >= ntaps - 1:
+            second = dsp.fir_f32_device(bd, xd[:, cut:].contiguous(), hist=xd[:, cut - (ntaps - 1):cut].contiguous())
+            assert np.array_equal(second.cpu().numpy().view(np.uint32), want[:, cut:].view(np.uint32))
+
+
+def test_single_precision_reference_literals(dsp, oracle, literals):
+    """The reference's test_lfilter in its single-precision form (dsp.hpp:1590-1597): lfilter<float> over the double
+    taps and data, within its 1e-6; an Inf tap does not reach the truncated sums at the start."""
+    t = literals["lfilter"]
+    w = dsp.firwin(t["numtaps"], t["cutoff"])
+    y = dsp.lfilter_f32(w, np.array(t["data"]))
+    assert np.max(np.abs(y.astype(np.float64) - np.array(t["expected"]))) < t["tol_f32"]
+    w2 = w.copy()
+    w2[40] = np.inf
+    x = oracle.fill_splitmix(3000, dsp.SEED, 0)
+    ref = oracle.lfilter_f32_from_f64(w2, x)
+    got = dsp.lfilter_f32(w2, x)
+    assert np.isfinite(ref[:40]).all() and np.array_equal(got.view(np.uint32), ref.view(np.uint32))

@@ -37,6 +37,9 @@ def test_lfilter_literals(oracle, literals):
     assert np.max(np.abs(y - np.array(t["expected"]))) < t["tol"]  # dsp.hpp:1583-1588
     y32 = oracle.lfilter_f32(w, t["data"])
     assert np.max(np.abs(y32.astype(np.float64) - np.array(t["expected"]))) < t["tol_f32"]
+    # what the reference's test really instantiates: lfilter<float> over its double taps and data (dsp.hpp:1590-1597)
+    y32 = oracle.lfilter_f32_from_f64(w, t["data"])
+    assert np.max(np.abs(y32.astype(np.float64) - np.array(t["expected"]))) < t["tol_f32"]
 
 
 @pytest.mark.parametrize("key,args", [
@@ -159,3 +162,7 @@ def test_fuzz_bit_exact_vs_reference(oracle, reference):
     b32 = rng.standard_normal(40).astype(np.float32)
     x32 = rng.standard_normal(333).astype(np.float32)
     assert np.array_equal(oracle.lfilter_f32(b32, x32).view(np.uint32), reference.lfilter_f32(b32, x32).view(np.uint32))
+    # lfilter<float> over double containers (the form the reference's own test uses): double products, float sums
+    b64, x64 = rng.standard_normal(40), rng.standard_normal(333)
+    assert np.array_equal(oracle.lfilter_f32_from_f64(b64, x64).view(np.uint32),
+                          reference.lfilter_f32_from_f64(b64, x64).view(np.uint32))
