@@ -19,4 +19,5 @@ pass sq2 SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_IN
 pass fetch FETCH_SIZE &&
 pass write WRITE_SIZE &&
 pass grbm GRBM_GUI_ACTIVE &&
+pass mfma SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CYCLES &&
 echo "profile ok: $OUT"

@@ -26,8 +26,11 @@ shutil.copy(glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv"))[0],
 out = {"command": "tools/profile.sh: rocprofv3 --kernel-trace --stats, then one --pmc pass per counter group, each around "
                   "`python3 bench.py --steps 5|2 --warmup 1 --no-cpu-baseline`",
        "workload": workload, "per_launch": {}, "kernel": None}
-for name in ("sq1", "sq2", "fetch", "write", "grbm"):
-    f = glob.glob(os.path.join(src, name, "*", "*_counter_collection.csv"))[0]
+for name in ("sq1", "sq2", "fetch", "write", "grbm", "mfma"):
+    found = glob.glob(os.path.join(src, name, "*", "*_counter_collection.csv"))
+    if not found:
+        continue   # older profile directories have no matrix-pipe pass
+    f = found[0]
     agg, disp, spans = collections.defaultdict(float), set(), {}
     for r in csv.DictReader(open(f)):
         if pattern in r["Kernel_Name"]:
@@ -50,6 +53,14 @@ out["derived"] = {
     "clock_ghz_from_grbm": pl["GRBM_GUI_ACTIVE"] / 8 / out["grbm_pass_avg_launch_ns"],
     "note_clock": "GRBM_GUI_ACTIVE sums the 8 XCDs; divided by 8 and by the launch duration in the same pass",
 }
+if "SQ_VALU_MFMA_BUSY_CYCLES" in pl:
+    simds = 1024.0   # 256 CUs x 4
+    clock_hz = out["derived"]["clock_ghz_from_grbm"] * 1e9
+    out["derived"]["mfma_busy_fraction"] = pl["SQ_VALU_MFMA_BUSY_CYCLES"] / (simds * clock_hz * out["grbm_pass_avg_launch_ns"] * 1e-9)
+    out["derived"]["mfma_flops_issued_per_launch"] = pl["SQ_INSTS_VALU_MFMA_MOPS_F64"] * 512.0
+    out["derived"]["note_mfma"] = ("SQ_VALU_MFMA_BUSY_CYCLES counts the cycles a SIMD's matrix pipe is occupied (16 per "
+                                   "v_mfma_f64_4x4x4_4b_f64); the fraction is that over SIMDs x clock x launch duration. "
+                                   "MOPS_F64 x 512 = flops issued, the band's zero columns included")
 json.dump(out, open(os.path.join(prof, f"{tag}_pmc_summary.json"), "w"), indent=1)
 tpath = os.path.join(prof, "pmc_traffic.json")
 tr = json.load(open(tpath)) if os.path.exists(tpath) else {}
