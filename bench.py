@@ -426,7 +426,26 @@ def small_allgather(dsp_amd, dist, torch, y, rank, world, fence, on_gpu: bool):
         t = torch.tensor([ms, 0.0 if ok else 1.0], dtype=torch.float64, device=mine.device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         recv = 8.0 * rows * n * (world - 1)
-        return {"ms": float(t[0]), "rows_per_rank": rows, "bytes_received_per_gpu": recv,
+        c_abi = None
+        if on_gpu:   # the same exchange through the library's own entry point (dspx_allgather_f64_dev over its RCCL communicator)
+            try:
+                box = [dsp_amd.Comm.unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(box, src=0)
+                comm = dsp_amd.Comm(box[0], world, rank)
+                full2 = comm.allgather(mine_dev)          # warm-up
+                fence()
+                t0 = time.perf_counter()
+                full2 = comm.allgather(mine_dev, out=full2)
+                fence()
+                ms2 = (time.perf_counter() - t0) * 1e3
+                same = bool(torch.equal(full2, full))
+                comm.close()
+                t2 = torch.tensor([ms2, 0.0 if same else 1.0], dtype=torch.float64, device=mine.device)
+                dist.all_reduce(t2, op=dist.ReduceOp.MAX)
+                c_abi = {"ms": float(t2[0]), "GB/s_per_gpu": recv / float(t2[0]) / 1e6, "equals_torch_gather": float(t2[1]) == 0.0}
+            except Exception as e:  # noqa: BLE001
+                c_abi = {"error": f"{type(e).__name__}: {e}"}
+        return {"ms": float(t[0]), "rows_per_rank": rows, "bytes_received_per_gpu": recv, "dspx_allgather_f64_dev": c_abi,
                 "GB/s_per_gpu": recv / float(t[0]) / 1e6, "matches_per_rank_checksums": float(t[1]) == 0.0,
                 "transport": "RCCL (nccl backend), device buffers" if on_gpu else "rehearsal backend, host copies",
                 "note": "all_gather_into_tensor of a slice of the result shards over the process group, outside the "

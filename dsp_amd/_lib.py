@@ -75,6 +75,11 @@ SIGNATURES = {
     "dspx_cwt_bank_apply_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_uint,
                                           C.c_void_p]),
     "dspx_cwt_bank_destroy": (None, [C.c_void_p]),
+    "dspx_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "dspx_comm_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "dspx_comm_ranks": (C.c_int, [C.c_void_p]),
+    "dspx_allgather_f64_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "dspx_comm_destroy": (None, [C.c_void_p]),
     "dspx_fill_splitmix_f64_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_uint64, C.c_uint64, C.c_void_p]),
     "dspx_checksum_f64_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_uint64, C.c_void_p, C.c_void_p]),
 }

@@ -357,3 +357,45 @@ def allgather_channels(y_local, nchan_total: int, group=None):
         rlo, rhi = channel_range(nchan_total, r, world)
         full[rlo:rhi] = recv[r * most: r * most + (rhi - rlo)]
     return full
+
+
+class Comm:
+    """RCCL communicator of the optional exchange step (dspx_comm_*): one process per GPU.  `Comm.unique_id()` on
+    rank 0, hand the bytes to every rank, then `Comm(id_bytes, nranks, rank)` on all ranks with their device current."""
+
+    ID_BYTES = 128
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = C.create_string_buffer(Comm.ID_BYTES)
+        check(lib().dspx_comm_unique_id(buf))
+        return buf.raw
+
+    def __init__(self, id_bytes: bytes, nranks: int, rank: int):
+        assert len(id_bytes) == Comm.ID_BYTES
+        h = C.c_void_p()
+        check(lib().dspx_comm_create(id_bytes, int(nranks), int(rank), C.byref(h)))
+        self._h, self.nranks, self.rank = h, int(nranks), int(rank)
+
+    def allgather(self, y_local, out=None):
+        """Every rank's contiguous float64 CUDA tensor `y_local` (equal shapes) -> [nranks * rows, ...] in rank order."""
+        import torch
+
+        assert y_local.is_cuda and y_local.dtype == torch.float64 and y_local.is_contiguous()
+        if out is None:
+            out = torch.empty((self.nranks * y_local.shape[0],) + tuple(y_local.shape[1:]), dtype=torch.float64,
+                              device=y_local.device)
+        assert out.is_contiguous() and out.numel() == self.nranks * y_local.numel() and out.dtype == torch.float64
+        check(lib().dspx_allgather_f64_dev(self._h, y_local.data_ptr(), out.data_ptr(), y_local.numel(), _stream_ptr()))
+        return out
+
+    def close(self):
+        if self._h:
+            lib().dspx_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

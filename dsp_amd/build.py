@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib", "libdspx.so")
-SOURCES = ["fir_kernels.hip", "iir_kernels.hip", "dspx_capi.hip", "dspx_cwt.hip"]
+SOURCES = ["fir_kernels.hip", "iir_kernels.hip", "dspx_capi.hip", "dspx_cwt.hip", "dspx_comm.hip"]
 HEADERS = [os.path.join(CSRC, "fir_kernels.h"), os.path.join(CSRC, "iir_kernels.h"), os.path.join(CSRC, "dspx_common.h"), os.path.join(ROOT, "include", "dspx.h"),
            os.path.join(ROOT, "include", "dsp.hpp")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++20", "-ffp-contract=off", "-fPIC", "-shared",

@@ -238,6 +238,23 @@ DSPX_API int dspx_cwt_bank_apply_dev(const dspx_cwt_bank* bank, const double* d_
                                      size_t row_stride, unsigned flags, void* stream);
 DSPX_API void dspx_cwt_bank_destroy(dspx_cwt_bank* bank);
 
+/* ---- optional exchange step: all-gather of result shards over RCCL ---------------------------------
+ * No counterpart in the reference (it has no devices).  The sharded filter needs no collective; callers that want
+ * every GPU to hold the whole result gather the shards afterwards: one process per GPU, rank r contributes `count`
+ * doubles at d_send and receives the shards of all ranks, in rank order, at d_recv (nranks * count doubles; d_send
+ * may be d_recv + rank*count).  Contiguous channel ranges of equal size (dspx_fir_plan with nchan a multiple of the
+ * device count) thus land in channel order.  RCCL is loaded at run time (the copy the process already holds, else
+ * librccl.so.1).  Rank 0 makes an id (DSPX_COMM_ID_BYTES opaque bytes) and hands it to the other ranks by any
+ * means (a file, a socket, MPI, torch.distributed); every rank then calls dspx_comm_create with its current device
+ * set -- collectively, like ncclCommInitRank, which it wraps.  dspx_allgather_f64_dev is asynchronous on `stream`. */
+#define DSPX_COMM_ID_BYTES 128
+typedef struct dspx_comm dspx_comm;
+DSPX_API int dspx_comm_unique_id(void* id_bytes);
+DSPX_API int dspx_comm_create(const void* id_bytes, int nranks, int rank, dspx_comm** comm);
+DSPX_API int dspx_comm_ranks(const dspx_comm* comm);
+DSPX_API int dspx_allgather_f64_dev(dspx_comm* comm, const double* d_send, double* d_recv, size_t count, void* stream);
+DSPX_API void dspx_comm_destroy(dspx_comm* comm);
+
 /* ---- deterministic synthetic data and checksums (benchmark / parity support) -----
  * d_x[i] = ((mix64(seed + (offset+i+1)*0x9E3779B97F4A7C15) >> 11) * 2^-52) - 1.0,
  * mix64 = the SplitMix64 finaliser; uniform in [-1, 1), exactly representable. */

@@ -183,3 +183,22 @@ def test_bench_two_ranks_without_a_launcher():
         out = lines[0]
         assert out["n_gpus"] == 2 and out["ranks_seen"] == 2 and out["scaling"] == scaling and out["value"] > 0
         assert out["allgather"].get("matches_per_rank_checksums") is True, out["allgather"]
+
+
+def test_rccl_allgather_entry_point_single_rank(dsp):
+    """dspx_comm_* / dspx_allgather_f64_dev: a communicator of one rank (all a one-GPU machine can hold; RCCL refuses
+    two ranks on one device) gathers a shard onto itself.  The N-rank exchange runs in bench.py --gpus N."""
+    import torch
+
+    ident = dsp.Comm.unique_id()
+    assert len(ident) == 128
+    comm = dsp.Comm(ident, 1, 0)
+    assert dsp.lib().dspx_comm_ranks(comm._h) == 1
+    y = torch.empty((7, 3001), dtype=torch.float64, device="cuda")
+    dsp.fill_splitmix(y, dsp.SEED, 5)
+    full = comm.allgather(y)
+    torch.cuda.synchronize()
+    assert full.shape == y.shape and torch.equal(full, y)
+    comm.close()
+    with pytest.raises(dsp.DspxError):
+        dsp.Comm(ident, 2, 5)
