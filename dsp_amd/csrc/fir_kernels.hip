@@ -72,6 +72,21 @@ typedef double dvec2 __attribute__((ext_vector_type(2)));
 // MI355X: a 2-tap filter, i.e. a scaled copy, moves 6.23 TB/s with it and 6.00 without).
 __device__ __forceinline__ dvec2 stream_load(const dvec2* p) { return __builtin_nontemporal_load(p); }
 __device__ __forceinline__ void stream_store(dvec2* p, dvec2 v) { __builtin_nontemporal_store(v, p); }
+// A wave-uniform pointer the compiler must keep in scalar registers: a memory instruction then takes it as its scalar
+// base with one shared per-lane offset, instead of a 64-bit per-lane address held in two vector registers.
+// The thread index as a value the compiler cannot compute ahead: what a phase derives from it (offsets, range checks)
+// is then formed where it is used instead of being carried in registers through the whole tile loop.
+__device__ __forceinline__ int fresh(int v) {
+    asm volatile("" : "+v"(v));
+    return v & (kBlock - 1);  // (tells the compiler the range again)
+}
+template <typename T> __device__ __forceinline__ auto scalar_base(T* p) {
+    typedef T __attribute__((address_space(1))) * global_ptr;  // (a pointer made from an integer would be a flat one)
+    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (global_ptr)(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ dvec2 stream_load(const dvec2 __attribute__((address_space(1))) * p) { return __builtin_nontemporal_load(p); }
 
 __device__ __forceinline__ bool not_finite(double v) {
     return (__double_as_longlong(v) & 0x7ff0000000000000ll) == 0x7ff0000000000000ll;
@@ -365,11 +380,12 @@ template <int OB> struct M4Geo {
     static constexpr int kTapIters = (kTapSlots + kBlock - 1) / kBlock;
     static constexpr int kSlots = kHalo + kTile;
     static constexpr int kPairs = (kSlots + 2 * (kSlots / kSeg)) / 2;
-    static constexpr int kOutPairs = (kTile + 2 * (kTile / kSeg)) / 2;
+    static constexpr int kOutStep = kSeg + 1;               // doubles between segments in the output buffer
+    static constexpr int kOutDoubles = (kTile / kSeg * kOutStep + 3) & ~1;  // (two more: bank mode reads c[q + 2])
     static constexpr int kStageIters = (kSlots / 2 + kBlock - 1) / kBlock;
     static constexpr int kResident = OB == 4 ? 2 : 4;       // workgroups per CU the grid is sized for
     static_assert(kHalo % kSeg == 0, "the image's pad groups start at the window's first slot");
-    static_assert(kResident * (kPairs * 16 + kOutPairs * 16 + kTapSlots * 8 + 16) <= 160 * 1024, "LDS of the resident workgroups");
+    static_assert(kResident * (kPairs * 16 + kOutDoubles * 8 + kTapSlots * 8 + 16) <= 160 * 1024, "LDS of the resident workgroups");
 };
 
 // What a workgroup needs to know about one tile (all wave-uniform).
@@ -383,7 +399,10 @@ struct M4Tile {
     int ntaps, odd;
 };
 
-template <int OB, bool VEC2, bool BANK>
+// SINGLE: lfilter mode with a filter that one window serves (the common case, up to 4 * kStageSteps - 2 taps): every
+// tile is one pass of the loop and the tap table stays in LDS for the whole launch, which the compiler is told at
+// compile time so that the per-tile code is a straight line.
+template <int OB, bool VEC2, bool BANK, bool SINGLE>
 __global__ __launch_bounds__(kBlock, OB == 4 ? 2 : 4) void fir_f64_mfma4_kernel(const double* __restrict__ taps,
                                                                                  const double* __restrict__ x,
                                                                                  const double* __restrict__ hist,
@@ -395,14 +414,21 @@ __global__ __launch_bounds__(kBlock, OB == 4 ? 2 : 4) void fir_f64_mfma4_kernel(
     // One LDS block, the tap table first: LDS instructions reach 64 KB from their address register, and the product
     // loop reads the table at constant distances from one pointer.
     constexpr int kTapDoubles = (G::kTapSlots + 1) & ~1;
-    __shared__ double2 lds[kTapDoubles / 2 + G::kPairs + G::kOutPairs + 1];
+    __shared__ double2 lds[kTapDoubles / 2 + G::kPairs + G::kOutDoubles / 2 + 1];
     double* const tapz = reinterpret_cast<double*>(lds);
     double2* const img = lds + kTapDoubles / 2;
-    double2* const outb = img + G::kPairs;
-    int* const bad_flag = reinterpret_cast<int*>(outb + G::kOutPairs);
+    double* const outd = reinterpret_cast<double*>(img + G::kPairs);
+    int* const bad_flag = reinterpret_cast<int*>(outd + G::kOutDoubles);
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const long long n = s.n;
+    // Sign of a 64-bit wave-uniform value by its high word: the scalar unit has no 64-bit ordered compare, and a
+    // compare on the vector unit costs this wave far more than its one instruction (see below).
+    auto negative = [](long long v) __attribute__((always_inline)) {
+        int hi = (int)((unsigned long long)v >> 32);
+        asm("" : "+s"(hi));  // (in a scalar register, and not to be read as v < 0 again)
+        return hi < 0;
+    };
 
     // Blocks b and b + 8 share an XCD (and its L2): XCD g owns a contiguous run of tile indices, and its workgroups
     // walk that run side by side (neighbouring tiles share a halo, which the XCD's L2 then serves).
@@ -455,9 +481,18 @@ __global__ __launch_bounds__(kBlock, OB == 4 ? 2 : 4) void fir_f64_mfma4_kernel(
         per = nstages > 1 ? (total + nstages - 1) / nstages : max(total, 1);
     };
     // In lfilter mode a filter that fits one window keeps its tap table in LDS for the whole launch.
+    static_assert(!(BANK && SINGLE), "a bank's rows differ in length");
     int total_steps, per_stage;
     stage_steps(BANK ? 0 : s.ntaps, total_steps, per_stage);
-    const bool taps_stay = !BANK && total_steps <= per_stage;
+    constexpr bool taps_stay = SINGLE;
+
+    // A wave's ordinary vector instructions are issued very slowly while the other waves of its SIMD issue matrix
+    // instructions back to back (measured with tools/issue_probe.hip: a dependent v_xor takes ~50 times as long next
+    // to three such waves; scalar instructions are not slowed).  Everything a tile does outside the product loop is
+    // therefore written to need as few vector-unit instructions as possible: per-lane addresses are formed once, below,
+    // and kept; memory instructions take a scalar base plus one of those offsets; LDS instructions take constant
+    // distances from them; range checks that do not hold for a whole tile are in branches of their own, whose per-lane
+    // arithmetic starts from fresh(tid) so that none of it is computed ahead and carried through the loop.
 
     // ---- the window in flight: samples (and taps) of (tile at position fk, first step fe0) on their way into
     // registers.  Image slot q <- sample pos0 - 4*e0 - kHalo + q, from the lowest pad group the products read; tap
@@ -470,9 +505,10 @@ __global__ __launch_bounds__(kBlock, OB == 4 ? 2 : 4) void fir_f64_mfma4_kernel(
     bool finterior = false;
     auto window_lo = [](int steps) __attribute__((always_inline)) { return (G::kHalo - 4 * (steps - 1)) & ~(G::kSeg - 1); };
     auto fetch_taps = [&](const M4Tile& t, int e0) __attribute__((always_inline)) {
+        const int ft = fresh(tid);
 #pragma unroll
         for (int r = 0; r < G::kTapIters; ++r) {
-            const int j = 4 * e0 - 3 + tid + r * kBlock;
+            const int j = 4 * e0 - 3 + ft + r * kBlock;
             T[r] = (j >= 0 && j < t.ntaps) ? t.tapsc[j] : 0.0;
         }
     };
@@ -481,7 +517,7 @@ __global__ __launch_bounds__(kBlock, OB == 4 ? 2 : 4) void fir_f64_mfma4_kernel(
         if (!taps_stay) fetch_taps(t, e0);
         const int qlo = window_lo(steps);
         const long long g_lo = t.pos0 - 4 * e0 - G::kHalo + qlo;
-        finterior = g_lo >= 0 && g_lo + (G::kSlots - qlo) <= n;
+        finterior = !negative(g_lo) && !negative(n - (g_lo + (G::kSlots - qlo)));
         if (!finterior) return;
         const int npairs = (G::kSlots - qlo) / 2;
         const double* src = t.xc + g_lo;  // wave-uniform
@@ -489,7 +525,7 @@ __global__ __launch_bounds__(kBlock, OB == 4 ? 2 : 4) void fir_f64_mfma4_kernel(
         for (int i = 0; i < G::kStageIters; ++i) {
             if (i < G::kStageIters - 1 || tid + i * kBlock < npairs) {
                 if constexpr (VEC2) {  // a long filter reads its samples once per window: those loads stay cacheable
-                    const dvec2* p = reinterpret_cast<const dvec2*>(src) + i * kBlock;
+                    const auto p = scalar_base(reinterpret_cast<const dvec2*>(src) + i * kBlock);
                     R[i] = taps_stay ? stream_load(p + (unsigned)tid) : p[(unsigned)tid];
                 } else {
                     const double* p = src + 2 * i * kBlock;
@@ -501,9 +537,10 @@ __global__ __launch_bounds__(kBlock, OB == 4 ? 2 : 4) void fir_f64_mfma4_kernel(
     const int stage_lane = tid + (tid >> (G::kShift - 1));  // where a thread's first pair goes, relative to the window's start
     constexpr int kPairStep = kBlock + (kBlock >> (G::kShift - 1));  // image distance of pairs kBlock apart
     auto put_taps = [&]() __attribute__((always_inline)) {
+        const int ft = fresh(tid);
 #pragma unroll
         for (int r = 0; r < G::kTapIters; ++r) {
-            const int i = tid + r * kBlock;
+            const int i = ft + r * kBlock;
             if (r < G::kTapIters - 1 || i < G::kTapSlots) tapz[i] = T[r];
         }
     };
@@ -512,8 +549,8 @@ __global__ __launch_bounds__(kBlock, OB == 4 ? 2 : 4) void fir_f64_mfma4_kernel(
         if (!taps_stay) put_taps();
         const int qlo = window_lo(fsteps);
         const int npairs = (G::kSlots - qlo) / 2;
-        dvec2* stage = reinterpret_cast<dvec2*>(img) + (qlo >> 1) + (qlo >> G::kShift) + stage_lane;
         if (finterior) {
+            dvec2* stage = reinterpret_cast<dvec2*>(img) + (qlo >> 1) + (qlo >> G::kShift) + stage_lane;
 #pragma unroll
             for (int i = 0; i < G::kStageIters; ++i)  // pair tid + i*kBlock: a constant distance per i
                 if (i < G::kStageIters - 1 || tid + i * kBlock < npairs) stage[i * kPairStep] = R[i];
@@ -521,12 +558,11 @@ __global__ __launch_bounds__(kBlock, OB == 4 ? 2 : 4) void fir_f64_mfma4_kernel(
             M4Tile t{};
             (void)locate(fk, t);
             const long long g_lo = t.pos0 - 4 * fe0 - G::kHalo + qlo;
+            const int ft = fresh(tid);
+            dvec2* stage = reinterpret_cast<dvec2*>(img) + (qlo >> 1) + (qlo >> G::kShift) + ft + (ft >> (G::kShift - 1));
 #pragma unroll 1
-            for (int i = 0; tid + i * kBlock < npairs; ++i) {
-                const int pi = tid + i * kBlock;
-                stage[i * kPairStep] =
-                    dvec2{sample_at(t.xc, t.hc, g_lo + 2 * pi, n, t.ntaps), sample_at(t.xc, t.hc, g_lo + 2 * pi + 1, n, t.ntaps)};
-            }
+            for (int pi = ft; pi < npairs; pi += kBlock, stage += kPairStep)
+                *stage = dvec2{sample_at(t.xc, t.hc, g_lo + 2 * pi, n, t.ntaps), sample_at(t.xc, t.hc, g_lo + 2 * pi + 1, n, t.ntaps)};
         }
     };
 
@@ -534,14 +570,15 @@ __global__ __launch_bounds__(kBlock, OB == 4 ? 2 : 4) void fir_f64_mfma4_kernel(
     const double* imgd = reinterpret_cast<const double*>(img);
     const double* w_home = imgd + (G::kHalo + wave * G::kWaveOut) / G::kSeg * G::kPadStep + G::kPadStep * (lane & 15) + (lane >> 4);
     const double* a_home = tapz + 3 + (lane & 3) - (lane >> 4);
-    // acc[rb] is output 4*rb + (lane >> 4) of segment lane & 15.  Segments 8..15 of a wave store every aligned pair of
-    // outputs swapped (index ^ 1): the 16 lanes of a ds_write_b64 group then fall into 16 different bank pairs
-    // (without it segments n and n + 8 collide), and a pair stays one aligned 16-byte unit for the readers, which
-    // swap it back.
-    double* o_home = reinterpret_cast<double*>(outb) + wave * (G::kWaveOut / G::kSeg * G::kPadStep) + G::kPadStep * (lane & 15) +
-                     ((lane >> 4) ^ ((lane >> 3) & 1));
-    const double2* g_home = outb + stage_lane;             // the pairs a thread stores to memory: tid + i*kBlock
-    const bool g_swap = OB == 2 && ((tid >> 7) & 1) != 0;  // OB == 4: pairs with odd i (compile-time)
+    // The output buffer holds tile output q at q + q / kSeg (one spare double per segment): acc[rb] is output
+    // 4*rb + (lane >> 4) of segment lane & 15, and with an odd distance between segments the 16 lanes of a ds_write_b64
+    // group fall into 16 different bank pairs.  It is read back 8 bytes per lane, lanes in output order.
+    double* o_home = outd + wave * (G::kWaveOut / G::kSeg * G::kOutStep) + G::kOutStep * (lane & 15) + (lane >> 4);
+    constexpr int kStores = G::kTile / kBlock;                                  // outputs per thread: tid + i*kBlock
+    constexpr int kOutRowStep = kBlock + kBlock / G::kSeg;                      // buffer distance of outputs kBlock apart
+    const double* g_home = outd + tid + (tid >> G::kShift);                     // output tid
+    const double* g_home1 = outd + (tid + 1) + ((tid + 1) >> G::kShift);        // bank mode: outputs tid + 1, tid + 2
+    const double* g_home2 = outd + (tid + 2) + ((tid + 2) >> G::kShift);
     if (tid < 2) bad_flag[tid] = 0;
 
     // What the epilogue needs of a tile; kept from the moment the tile's first window is fetched.
@@ -568,7 +605,31 @@ __global__ __launch_bounds__(kBlock, OB == 4 ? 2 : 4) void fir_f64_mfma4_kernel(
         }
         cur_out = out_of(first_tile);
         fetch(first_tile, k, 0, min(per_stage, max(total_steps, 1)));
+        commit();
     }
+    // A finished tile's results wait in O[] and are stored after the next window's loads have been issued: the step that
+    // takes a window from registers to LDS waits for every memory instruction issued before it, and what was issued a
+    // whole window earlier has long been done, while stores issued just before it would be waited for until memory
+    // has acknowledged them.
+    constexpr int kOutputs = BANK ? G::kBankStride : G::kTile;
+    double O[kStores];
+    double* pend_yt = nullptr;
+    int pend_left = 0;  // outputs of the tile that exist, at most kOutputs
+    bool stores_due = false;
+    auto store_tile = [&]() __attribute__((always_inline)) {
+        if (pend_left >= kOutputs) {  // all of the tile
+#pragma unroll
+            for (int i = 0; i < kStores; ++i) {
+                const auto p = scalar_base(pend_yt + i * kBlock);
+                if (!BANK || i < kStores - 1 || tid < kBlock - (G::kTile - G::kBankStride)) __builtin_nontemporal_store(O[i], p + (unsigned)tid);
+            }
+        } else {
+            const int ft = fresh(tid);
+#pragma unroll
+            for (int i = 0; i < kStores; ++i)
+                if (ft + i * kBlock < pend_left) pend_yt[ft + i * kBlock] = O[i];
+        }
+    };
 
     double acc[RB];
 #pragma unroll
@@ -577,11 +638,10 @@ __global__ __launch_bounds__(kBlock, OB == 4 ? 2 : 4) void fir_f64_mfma4_kernel(
     unsigned parity = 0;
     // One pass per window: a tile has one unless its filter is longer than a window reaches.
     for (bool more = true; more;) {
-        const int steps = fsteps;
-        commit();  // everybody is past the previous window's products (barriers below)
+        const int steps = SINGLE ? total_steps : fsteps;  // the window in the image
         // start the loads of the window after this one: the next stage of this tile, or the next tile
         const int e_next = e0 + steps;
-        const bool tile_done = e_next >= total_steps;
+        const bool tile_done = SINGLE || e_next >= total_steps;
         unsigned kn = k;
         int next_total = total_steps, next_per = per_stage;
         {
@@ -602,6 +662,8 @@ __global__ __launch_bounds__(kBlock, OB == 4 ? 2 : 4) void fir_f64_mfma4_kernel(
                 fetch(t, kn, ne0, min(next_per, max(next_total, 1) - ne0));
             }
         }
+        if (stores_due) store_tile();
+        stores_due = false;
         __syncthreads();
 
         if (total_steps > 0) {
@@ -652,10 +714,11 @@ __global__ __launch_bounds__(kBlock, OB == 4 ? 2 : 4) void fir_f64_mfma4_kernel(
         if (!tile_done) {
             e0 = e_next;
             __syncthreads();  // the image is rewritten for the next window
+            commit();         // (a tile's last window is never the launch's last: `more` holds)
             continue;
         }
 
-        // ---- accumulators -> second LDS buffer ----
+        // ---- accumulators -> output buffer ----
         // The zero taps at the band's edges multiply real samples and the zero samples in front of a channel multiply
         // real taps; 0 * Inf (or NaN) is NaN where the reference adds nothing.  Any such product leaves a non-finite
         // accumulator, and then so is the sum of the lane's accumulators: a tile with one is computed again by the plain
@@ -675,16 +738,16 @@ __global__ __launch_bounds__(kBlock, OB == 4 ? 2 : 4) void fir_f64_mfma4_kernel(
         parity ^= 1u;
 
         double* __restrict__ yt = cur_out.yt;
-        const long long left = cur_out.left;
-        constexpr int kOutputs = BANK ? G::kBankStride : G::kTile;
+        const int left = negative(cur_out.left - kOutputs) ? (int)cur_out.left : kOutputs;
         if (bad) {
             // one output at a time, every sample from memory again (rare and slow by design)
             M4Tile t{};
             (void)locate(k, t);
-            double* outd = reinterpret_cast<double*>(outb);
             const int extra = BANK ? 1 + t.odd : 0;  // bank mode needs c one or two samples past the tile
+            const int ft = fresh(tid);
             __syncthreads();
-            for (int o = tid; o < kOutputs + extra + 1; o += kBlock) {
+#pragma unroll 1
+            for (int o = ft; o < kOutputs + extra + 1; o += kBlock) {
                 double sum = 0.0;
                 for (int j = 0; j < t.ntaps; ++j) {
                     const long long g = t.pos0 + o - j;
@@ -696,50 +759,34 @@ __global__ __launch_bounds__(kBlock, OB == 4 ? 2 : 4) void fir_f64_mfma4_kernel(
                 outd[o] = sum;
             }
             __syncthreads();
-            for (int o = tid; o < kOutputs; o += kBlock) {
-                if (o < left) yt[o] = BANK ? (outd[o + t.odd + 1] - outd[o + t.odd]) * t.post : outd[o];
-            }
+#pragma unroll 1
+            for (int o = ft; o < left; o += kBlock) yt[o] = BANK ? (outd[o + t.odd + 1] - outd[o + t.odd]) * t.post : outd[o];
             __syncthreads();  // the buffer is free for the next tile
         } else {
-            auto out_pair = [&](int i) __attribute__((always_inline)) {  // outputs 2*pi, 2*pi + 1 of the tile, pi = tid + i*kBlock
-                const double2 v = g_home[i * kPairStep];
-                const bool swapped = OB == 4 ? (i & 1) != 0 : g_swap;
-                return swapped ? make_double2(v.y, v.x) : v;
-            };
-            const bool whole = !BANK && left >= G::kTile;
+            // the results wait in registers; stored while the next window's products run
 #pragma unroll
-            for (int i = 0; i < G::kTile / 2 / kBlock; ++i) {
-                const int pi = tid + i * kBlock;
-                double2 o = out_pair(i);
+            for (int i = 0; i < kStores; ++i) {
                 if constexpr (BANK) {
-                    // (c[i+1] - c[i]) * factor, shifted by one when the advance was rounded down
-                    double2 c23;
-                    if (i + 1 < G::kTile / 2 / kBlock || tid + 1 < kBlock) {
-                        const int pn = pi + 1;
-                        const double2 v = outb[pn + (pn >> (G::kShift - 1))];
-                        c23 = ((pn >> (G::kShift - 1)) & 8) ? make_double2(v.y, v.x) : v;
+                    // (c[q+1] - c[q]) * factor, shifted by one when the advance was rounded down (wave-uniform)
+                    const double c0 = g_home[i * kOutRowStep], c1 = g_home1[i * kOutRowStep];
+                    if (cur_out.odd) {
+                        const double c2 = (i < kStores - 1 || tid < kBlock - 2) ? g_home2[i * kOutRowStep] : c1;  // (never stored)
+                        O[i] = (c2 - c1) * cur_out.post;
                     } else {
-                        c23 = o;  // the tile's last pair is never stored
+                        O[i] = (c1 - c0) * cur_out.post;
                     }
-                    o = cur_out.odd ? make_double2((c23.x - o.y) * cur_out.post, (c23.y - c23.x) * cur_out.post)
-                                    : make_double2((o.y - o.x) * cur_out.post, (c23.x - o.y) * cur_out.post);
-                    if (2 * pi >= G::kBankStride) continue;
-                }
-                dvec2* dst = reinterpret_cast<dvec2*>(yt) + i * kBlock;  // wave-uniform
-                if (whole || 2 * pi + 1 < left) {
-                    if constexpr (VEC2)
-                        stream_store(dst + (unsigned)tid, dvec2{o.x, o.y});
-                    else
-                        yt[2 * pi] = o.x, yt[2 * pi + 1] = o.y;
-                } else if (2 * pi < left) {
-                    yt[2 * pi] = o.x;
+                } else {
+                    O[i] = g_home[i * kOutRowStep];
                 }
             }
+            pend_yt = yt, pend_left = left, stores_due = true;
         }
+        if (more) commit();  // everybody is past this tile's products
         k = kn, e0 = 0;
         cur_out = nxt_out;
         total_steps = next_total, per_stage = next_per;
     }
+    if (stores_due) store_tile();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -863,10 +910,20 @@ static void launch_mfma_variant(const double* taps, const double* x, const doubl
     using G = M4Geo<kMatrixOB>;
     const unsigned per_xcd = std::min((shape.total_tiles + 7) / 8, compute_units() * G::kResident / 8);
     const dim3 grid(8 * std::max(per_xcd, 1u)), block(kBlock);
+    const bool single = !BANK && shape.ntaps > 0 && (shape.ntaps + 2) / 4 + 1 <= G::kStageSteps;  // one window per tile
+    if constexpr (!BANK) {
+        if (single) {
+            if (vec2)
+                hipLaunchKernelGGL((fir_f64_mfma4_kernel<kMatrixOB, true, false, true>), grid, block, 0, stream, taps, x, hist, y, bank, shape);
+            else
+                hipLaunchKernelGGL((fir_f64_mfma4_kernel<kMatrixOB, false, false, true>), grid, block, 0, stream, taps, x, hist, y, bank, shape);
+            return;
+        }
+    }
     if (vec2)
-        hipLaunchKernelGGL((fir_f64_mfma4_kernel<kMatrixOB, true, BANK>), grid, block, 0, stream, taps, x, hist, y, bank, shape);
+        hipLaunchKernelGGL((fir_f64_mfma4_kernel<kMatrixOB, true, BANK, false>), grid, block, 0, stream, taps, x, hist, y, bank, shape);
     else
-        hipLaunchKernelGGL((fir_f64_mfma4_kernel<kMatrixOB, false, BANK>), grid, block, 0, stream, taps, x, hist, y, bank, shape);
+        hipLaunchKernelGGL((fir_f64_mfma4_kernel<kMatrixOB, false, BANK, false>), grid, block, 0, stream, taps, x, hist, y, bank, shape);
 }
 
 hipError_t launch_fir_mfma_f64(const double* taps, const double* x, const double* hist, double* y,
