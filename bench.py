@@ -184,7 +184,7 @@ def run_cwt(args, rank, world, dev, dist, red_dev, ranks_seen=1):
         "roofline": {"bound": "mfma", "achieved": flops / sec / 1e12, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
                      "frac": flops / sec / 1e12 / PEAK_FP64_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                      "kernel": "fir_f64_kernel (bank mode, vector pipe)" if args.vector or args.exact else
-                               "fir_f64_mfma_kernel + fir_f64_kernel (bank mode; rows of >= 96 taps on the matrix pipe)",
+                               "fir_f64_mfma4_kernel + fir_f64_kernel (bank mode; rows of >= 56 taps on the matrix pipe)",
                      "kernel_ms": kern_ms,
                      "note": "FP64 FMA; algorithmic flops = 2 * sum of per-scale tap counts per input sample"},
         "roofline_other": {"bound": "hbm", "achieved": bytes_alg / sec / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
@@ -576,7 +576,7 @@ def main() -> None:
 
     if rank == 0:
         matrix = not args.exact and not args.vector and numtaps >= dsp_amd.MATRIX_PIPE_MIN_TAPS
-        kernel_name = "fir_f64_mfma_kernel (v_mfma_f64_16x16x4_f64)" if matrix else "fir_f64_kernel (v_fma_f64)"
+        kernel_name = "fir_f64_mfma4_kernel (v_mfma_f64_4x4x4_4b_f64)" if matrix else "fir_f64_kernel (v_fma_f64)"
         outputs_per_launch = nchan * n_local
         traffic, traffic_src = (load_traffic(args.workload) if (n_local == n and nchan == WORKLOADS[args.workload][0])
                                 else (None, "this rank's shard is not the profiled launch"))

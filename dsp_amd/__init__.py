@@ -1,7 +1,8 @@
 """dsp_amd: MI355X (gfx950) FIR engine behind dsp::firwin -> dsp::lfilter(b, 1.0, x).
 
 Layout:
-  csrc/        HIP kernels (fir_kernels.hip) and the extern "C" ABI (dspx_capi.hip)
+  csrc/        HIP kernels (fir_kernels.hip, iir_kernels.hip) and the extern "C" ABI (dspx_capi.hip, dspx_cwt.hip,
+               dspx_comm.hip)
   lib/         the built libdspx.so (in-tree, not tracked by git)
   build.py     hipcc recipe
   _lib.py      ctypes loader (raises if the library is missing; no CPU fallback)
