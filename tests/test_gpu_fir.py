@@ -76,7 +76,10 @@ def test_ragged_and_short_vs_reference_outputs(dsp, oracle, golden):
 
 # ---- tap-count and length sweeps against the oracle ----
 
-@pytest.mark.parametrize("ntaps", [1, 2, 7, 8, 15, 16, 17, 31, 32, 33, 100, 255, 256, 257, 300, 511, 512, 513, 1041])
+# (25 / 26: fewer than / exactly one full group of matrix-pipe steps; 281 / 282: the longest filter one window
+# serves / the shortest that takes two)
+@pytest.mark.parametrize("ntaps", [1, 2, 7, 8, 15, 16, 17, 25, 26, 31, 32, 33, 57, 100, 255, 256, 257, 281, 282, 283, 300, 511, 512, 513,
+                                   1041])
 def test_tap_count_sweep(dsp, oracle, ntaps):
     rng = np.random.default_rng(ntaps)
     b = rng.standard_normal(ntaps)
