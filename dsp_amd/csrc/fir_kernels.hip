@@ -364,8 +364,9 @@ __global__ __launch_bounds__(kBlock) void fir_f64_kernel(const double* __restric
 //
 // Workgroups are persistent: the grid holds a few workgroups per CU and each walks its share of the tiles.  While the
 // products of one window run, the global loads of the next window (the next stage of a long filter, or the next
-// tile) are already in flight into registers; they are written to LDS when the products are done.  Results leave
-// through a second LDS buffer with plain stores nobody waits for.  Per window a workgroup meets at two barriers.
+// tile) are already in flight into registers; they are written to LDS when the products are done.  Results pass
+// through a second LDS buffer into registers and are stored one pass later, so that nothing ever waits for a store
+// to be acknowledged.  Per window a workgroup meets at two barriers.
 template <int OB> struct M4Geo {
     static constexpr int kSeg = 16 * OB;                    // outputs per segment (4 * OB row blocks of four) = pad group
     static constexpr int kPadStep = kSeg + 2;               // doubles between segments in the image
@@ -399,7 +400,7 @@ struct M4Tile {
     int ntaps, odd;
 };
 
-// SINGLE: lfilter mode with a filter that one window serves (the common case, up to 4 * kStageSteps - 2 taps): every
+// SINGLE: lfilter mode with a filter that one window serves (the common case, up to 4 * kStageSteps - 3 taps): every
 // tile is one pass of the loop and the tap table stays in LDS for the whole launch, which the compiler is told at
 // compile time so that the per-tile code is a straight line.
 template <int OB, bool VEC2, bool BANK, bool SINGLE>
