@@ -415,11 +415,10 @@ __global__ __launch_bounds__(kBlock, OB == 4 ? 2 : 4) void fir_f64_mfma4_kernel(
     // One LDS block, the tap table first: LDS instructions reach 64 KB from their address register, and the product
     // loop reads the table at constant distances from one pointer.
     constexpr int kTapDoubles = (G::kTapSlots + 1) & ~1;
-    __shared__ double2 lds[kTapDoubles / 2 + G::kPairs + G::kOutDoubles / 2 + 1];
+    __shared__ double2 lds[kTapDoubles / 2 + G::kPairs + G::kOutDoubles / 2];
     double* const tapz = reinterpret_cast<double*>(lds);
     double2* const img = lds + kTapDoubles / 2;
     double* const outd = reinterpret_cast<double*>(img + G::kPairs);
-    int* const bad_flag = reinterpret_cast<int*>(outd + G::kOutDoubles);
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const long long n = s.n;
@@ -580,7 +579,6 @@ __global__ __launch_bounds__(kBlock, OB == 4 ? 2 : 4) void fir_f64_mfma4_kernel(
     const double* g_home = outd + tid + (tid >> G::kShift);                     // output tid
     const double* g_home1 = outd + (tid + 1) + ((tid + 1) >> G::kShift);        // bank mode: outputs tid + 1, tid + 2
     const double* g_home2 = outd + (tid + 2) + ((tid + 2) >> G::kShift);
-    if (tid < 2) bad_flag[tid] = 0;
 
     // What the epilogue needs of a tile; kept from the moment the tile's first window is fetched.
     struct Out {
@@ -636,7 +634,6 @@ __global__ __launch_bounds__(kBlock, OB == 4 ? 2 : 4) void fir_f64_mfma4_kernel(
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) acc[rb] = 0.0;
     int e0 = 0;
-    unsigned parity = 0;
     // One pass per window: a tile has one unless its filter is longer than a window reaches.
     for (bool more = true; more;) {
         const int steps = SINGLE ? total_steps : fsteps;  // the window in the image
@@ -722,66 +719,57 @@ __global__ __launch_bounds__(kBlock, OB == 4 ? 2 : 4) void fir_f64_mfma4_kernel(
         // ---- accumulators -> output buffer ----
         // The zero taps at the band's edges multiply real samples and the zero samples in front of a channel multiply
         // real taps; 0 * Inf (or NaN) is NaN where the reference adds nothing.  Any such product leaves a non-finite
-        // accumulator, and then so is the sum of the lane's accumulators: a tile with one is computed again by the plain
-        // loop below, which adds exactly the reference's products.  (A sum of finite values that overflows only sends
-        // a tile there needlessly.)
+        // accumulator, and then so is the sum of the lane's accumulators.  A wave that finds one computes its own
+        // 16 * kSeg values again with a plain loop that adds exactly the reference's products, and puts them into
+        // the output buffer in place of the accumulators: no other wave needs to know.  (A sum of finite values
+        // that overflows only sends a wave there needlessly.)
         double probe = acc[0];
 #pragma unroll
-        for (int rb = 0; rb < RB; ++rb) {
-            if (rb) probe += acc[rb];
-            o_home[4 * rb] = acc[rb];
-            acc[rb] = 0.0;
-        }
-        if (not_finite(probe)) bad_flag[parity] = 1;
-        __syncthreads();  // also: everybody is past this tile's products
-        const bool bad = bad_flag[parity] != 0;  // workgroup-uniform
-        if (tid == 0) bad_flag[parity ^ 1u] = 0;  // not written again before the next tile's barriers
-        parity ^= 1u;
-
-        double* __restrict__ yt = cur_out.yt;
-        const int left = negative(cur_out.left - kOutputs) ? (int)cur_out.left : kOutputs;
-        if (bad) {
-            // one output at a time, every sample from memory again (rare and slow by design)
+        for (int rb = 1; rb < RB; ++rb) probe += acc[rb];
+        if (__builtin_amdgcn_ballot_w64(not_finite(probe)) != 0) {
+            // one value at a time, every sample from memory again (rare and slow by design)
             M4Tile t{};
             (void)locate(k, t);
-            const int extra = BANK ? 1 + t.odd : 0;  // bank mode needs c one or two samples past the tile
             const int ft = fresh(tid);
-            __syncthreads();
 #pragma unroll 1
-            for (int o = ft; o < kOutputs + extra + 1; o += kBlock) {
+            for (int q = (ft >> 6) * G::kWaveOut + (ft & 63); q < ((ft >> 6) + 1) * G::kWaveOut; q += 64) {
                 double sum = 0.0;
                 for (int j = 0; j < t.ntaps; ++j) {
-                    const long long g = t.pos0 + o - j;
+                    const long long g = t.pos0 + q - j;
                     if (g >= 0 && g < n)
                         sum = __builtin_fma(t.tapsc[j], t.xc[g], sum);
                     else if (g < 0 && t.hc != nullptr && g >= -(long long)(t.ntaps - 1))
                         sum = __builtin_fma(t.tapsc[j], t.hc[(t.ntaps - 1) + g], sum);
                 }
-                outd[o] = sum;
+                outd[q + (q >> G::kShift)] = sum;
             }
-            __syncthreads();
-#pragma unroll 1
-            for (int o = ft; o < left; o += kBlock) yt[o] = BANK ? (outd[o + t.odd + 1] - outd[o + t.odd]) * t.post : outd[o];
-            __syncthreads();  // the buffer is free for the next tile
         } else {
-            // the results wait in registers; stored while the next window's products run
 #pragma unroll
-            for (int i = 0; i < kStores; ++i) {
-                if constexpr (BANK) {
-                    // (c[q+1] - c[q]) * factor, shifted by one when the advance was rounded down (wave-uniform)
-                    const double c0 = g_home[i * kOutRowStep], c1 = g_home1[i * kOutRowStep];
-                    if (cur_out.odd) {
-                        const double c2 = (i < kStores - 1 || tid < kBlock - 2) ? g_home2[i * kOutRowStep] : c1;  // (never stored)
-                        O[i] = (c2 - c1) * cur_out.post;
-                    } else {
-                        O[i] = (c1 - c0) * cur_out.post;
-                    }
-                } else {
-                    O[i] = g_home[i * kOutRowStep];
-                }
-            }
-            pend_yt = yt, pend_left = left, stores_due = true;
+            for (int rb = 0; rb < RB; ++rb) o_home[4 * rb] = acc[rb];
         }
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) acc[rb] = 0.0;
+        __syncthreads();  // the tile's values are in the output buffer, and everybody is past its products
+
+        // the results wait in registers; stored while the next window's products run
+        double* __restrict__ yt = cur_out.yt;
+        const int left = negative(cur_out.left - kOutputs) ? (int)cur_out.left : kOutputs;
+#pragma unroll
+        for (int i = 0; i < kStores; ++i) {
+            if constexpr (BANK) {
+                // (c[q+1] - c[q]) * factor, shifted by one when the advance was rounded down (wave-uniform)
+                const double c0 = g_home[i * kOutRowStep], c1 = g_home1[i * kOutRowStep];
+                if (cur_out.odd) {
+                    const double c2 = (i < kStores - 1 || tid < kBlock - 2) ? g_home2[i * kOutRowStep] : c1;  // (never stored)
+                    O[i] = (c2 - c1) * cur_out.post;
+                } else {
+                    O[i] = (c1 - c0) * cur_out.post;
+                }
+            } else {
+                O[i] = g_home[i * kOutRowStep];
+            }
+        }
+        pend_yt = yt, pend_left = left, stores_due = true;
         if (more) commit();  // everybody is past this tile's products
         k = kn, e0 = 0;
         cur_out = nxt_out;
