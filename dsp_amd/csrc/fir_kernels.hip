@@ -27,6 +27,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 #include "fir_kernels.h"
 
@@ -779,6 +780,363 @@ __global__ __launch_bounds__(kBlock, OB == 4 ? 2 : 4) void fir_f64_mfma4_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
+// Wave-autonomous form of the matrix-pipe kernel for lfilter mode with a filter that one window serves (up to
+// 4 * kStageSteps - 3 = 281 taps) over 16-byte aligned buffers.  Same products, same order, same bits as
+// fir_f64_mfma4_kernel; what differs is who shares what:
+//   * every WAVE has an LDS image of its own (halo + 512 outputs' worth of samples) and walks a run of consecutive
+//     512-output chunks of one channel.  Nothing but the read-only tap table is shared between the waves of a
+//     workgroup, so there is no workgroup barrier after the table has been written: the LDS instructions of one wave
+//     execute in order, which is all the hand-over between a wave's own phases needs;
+//   * the halo of chunk k + 1 is the tail of chunk k's image: it is moved inside LDS (at most three 16-byte reads
+//     and writes per lane), so every sample of a run is fetched from memory exactly once, 64 bytes per lane and chunk;
+//   * results are transposed through the front of the wave's own image (dead once the products are done), read back
+//     in output order, 512 contiguous bytes per store instruction, and stored one chunk late like in the
+//     workgroup-tiled kernel.
+// Per chunk a wave issues, besides its matrix instructions, 4 loads, 8 stores, 26 LDS instructions and about two
+// dozen vector instructions, and waits for nobody but itself.
+#ifndef M4W_PRIO
+#define M4W_PRIO 0
+#endif
+#ifdef M4W_DYN
+__device__ unsigned g_m4w_counter[1];
+#endif
+struct FirRuns {
+    unsigned long long div_magic;  // run / runs_per_chan == (run * div_magic) >> div_shift
+    unsigned div_shift;
+    unsigned runs_per_chan;        // a channel's chunks are cut into this many runs ...
+    unsigned run_chunks;           // ... of this many chunks (the last one may be shorter)
+    unsigned chunks_per_chan;      // ceil(n / 512)
+    unsigned total_runs;           // nchan * runs_per_chan
+};
+
+__device__ __forceinline__ void wave_fence() {
+    // Orders this wave's LDS accesses as written (other lanes of the wave read what this lane wrote); the hardware
+    // executes a wave's LDS instructions in order, so nothing is emitted for it.
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+#ifdef DSPX_M4W_TIMING
+// Development build only: per-wave cycle counts of the phases of a chunk (tools/m4w_timing.py reads them).
+__device__ unsigned long long g_m4w_timing[16 * 8192];
+__device__ __forceinline__ unsigned long long stamp() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#endif
+
+template <int RESIDENT>
+__global__ __launch_bounds__(kBlock, RESIDENT) void fir_f64_mfma4w_kernel(const double* __restrict__ taps,
+                                                                           const double* __restrict__ x,
+                                                                           const double* __restrict__ hist,
+                                                                           double* __restrict__ y, FirShape s, FirRuns rn) {
+    using G = M4Geo<2>;
+    constexpr int RB = 8;                                        // row blocks of four outputs per segment
+    constexpr int kChunk = G::kWaveOut;                          // outputs per wave and chunk (512)
+    constexpr int kHaloGroups = G::kHalo / G::kSeg;              // 9
+    constexpr int kImgGroups = (G::kHalo + kChunk) / G::kSeg;    // 25 pad groups of 32 slots (34 doubles) per image
+    constexpr int kGroupPairs = G::kPadStep / 2;                 // 17
+    constexpr int kImgPairs = kImgGroups * kGroupPairs;          // 425 pairs = 6800 bytes per wave
+    constexpr int kTapDoubles = (G::kTapSlots + 1) & ~1;
+    constexpr int kBodyIters = kChunk / 2 / 64;                  // 16-byte loads per lane and chunk (4)
+    constexpr int kHaloIters = (kHaloGroups * kGroupPairs + 63) / 64;          // 3
+    constexpr int kFirstIters = ((G::kHalo + kChunk) / 2 + 63) / 64;           // 7
+    constexpr int kStores = kChunk / 64;                         // 8
+    static_assert(kChunk / G::kSeg * G::kOutStep <= (kImgGroups - kHaloGroups) * G::kPadStep,
+                  "the transposed results fit in the body's place");
+    __shared__ double2 lds[kTapDoubles / 2 + (kBlock / 64) * kImgPairs];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    double* const tapz = reinterpret_cast<double*>(lds);
+    dvec2* const imgw = reinterpret_cast<dvec2*>(lds + kTapDoubles / 2 + wave * kImgPairs);
+    double* const imgd = reinterpret_cast<double*>(imgw);
+    const long long n = s.n;
+    const int ntaps = s.ntaps;
+    auto negative = [](long long v) __attribute__((always_inline)) {
+        int hi = (int)((unsigned long long)v >> 32);
+        asm("" : "+s"(hi));
+        return hi < 0;
+    };
+
+    // tap slot i <- tap i - 3 (zero outside the filter), once per launch
+#pragma unroll
+    for (int r = 0; r < G::kTapIters; ++r) {
+        const int i = tid + r * kBlock, j = i - 3;
+        if (i < G::kTapSlots) tapz[i] = (j >= 0 && j < ntaps) ? taps[j] : 0.0;
+    }
+    __syncthreads();
+
+    const int steps = (ntaps + 2) / 4 + 1;                                        // <= kStageSteps
+    const int qlo = (G::kHalo - 4 * (steps - 1)) & ~(G::kSeg - 1);                // lowest image slot the products read
+    const int hgroups = (G::kHalo - qlo) / G::kSeg;                               // pad groups of halo in use (1..9)
+    const int hpairs = hgroups * kGroupPairs;
+
+    // per-lane LDS addresses, formed once
+    const double* w_home = imgd + kHaloGroups * G::kPadStep + G::kPadStep * (lane & 15) + (lane >> 4);
+    const double* a_home = tapz + 3 + (lane & 3) - (lane >> 4);
+    // results pass through the body's place in the image, output q at q + q / 32 (one spare double per segment)
+    double* o_home = imgd + kHaloGroups * G::kPadStep + G::kOutStep * (lane & 15) + (lane >> 4);   // acc[rb] -> o_home[4 * rb]
+    const double* g_home = imgd + kHaloGroups * G::kPadStep + lane + (lane >> G::kShift);           // output lane + 64 j at g_home[66 j]
+    constexpr int kBackStep = 64 + 64 / G::kSeg;
+    const dvec2* t_src = imgw + (kImgGroups - hgroups) * kGroupPairs + lane;      // halo carry: pair lane + 64 i
+    dvec2* t_dst = imgw + (kHaloGroups - hgroups) * kGroupPairs + lane;
+    dvec2* b_dst = imgw + kHaloGroups * kGroupPairs + lane + (lane >> 4);         // body pair lane + 64 i at b_dst[68 i]
+    dvec2* f_dst = imgw + (qlo / G::kSeg) * kGroupPairs + lane + (lane >> 4);     // first window: pair lane + 64 i from qlo
+    constexpr int kPairStep = 64 + 64 / 16;
+
+    double O[kStores];
+    double* pend_yt = nullptr;
+    int pend_left = 0;
+    bool stores_due = false;
+    auto store_chunk = [&]() __attribute__((always_inline)) {
+        if (pend_left >= kChunk) {
+#pragma unroll
+            for (int j = 0; j < kStores; ++j) __builtin_nontemporal_store(O[j], scalar_base(pend_yt + 64 * j) + (unsigned)lane);
+        } else {
+            const int fl = fresh(lane) & 63;
+#pragma unroll
+            for (int j = 0; j < kStores; ++j)
+                if (fl + 64 * j < pend_left) pend_yt[fl + 64 * j] = O[j];
+        }
+    };
+
+    double acc[RB];
+#if M4W_PRIO == 2
+    unsigned prio_cnt = 0;
+    const unsigned prio_slot = __builtin_amdgcn_s_getreg((3 << 11) | 4);  // HW_ID.wave_id
+#endif
+
+    const unsigned nwaves = gridDim.x * (kBlock / 64);
+#ifdef DSPX_M4W_TIMING
+    unsigned long long t_prod = 0, t_probe = 0, t_rest = 0, t_last = 0, n_chunks = 0, t_64 = 0;
+    const unsigned long long t_begin = stamp();
+    const unsigned long long r_begin = __builtin_amdgcn_s_memrealtime();
+#endif
+#ifdef M4W_DYN
+    // development variant: runs handed out by a counter (zeroed by the host before the launch), first come first served
+    unsigned run = blockIdx.x * (kBlock / 64) + wave;
+    for (; run < rn.total_runs;) {
+        unsigned nxt = 0;
+        if (lane == 0) nxt = atomicAdd(g_m4w_counter, 1u);
+        const unsigned run_next = nwaves + (unsigned)__builtin_amdgcn_readfirstlane((int)nxt);
+#else
+    for (unsigned run = blockIdx.x * (kBlock / 64) + wave; run < rn.total_runs; run += nwaves) {
+#endif
+        const unsigned chan = (unsigned)(((unsigned long long)run * rn.div_magic) >> rn.div_shift);
+        const unsigned c0 = (run - chan * rn.runs_per_chan) * rn.run_chunks;
+        const unsigned c1 = min(c0 + rn.run_chunks, rn.chunks_per_chan);
+        const double* __restrict__ xc = x + (unsigned long long)chan * s.x_stride;
+        const double* __restrict__ hc = hist ? hist + (unsigned long long)chan * s.hist_stride : nullptr;
+        double* __restrict__ yc = y + (unsigned long long)chan * s.y_stride;
+
+        // ---- the run's first window: image slot q <- sample 512*c0 - kHalo + q for q >= qlo ----
+        {
+            const long long start = (long long)c0 * kChunk;
+            const long long g_lo = start - G::kHalo + qlo;
+            const int npairs = (G::kHalo + kChunk - qlo) / 2;
+            if (!negative(g_lo) && !negative(n - (start + kChunk))) {
+                const dvec2* src = reinterpret_cast<const dvec2*>(xc + g_lo);
+                dvec2 F[kFirstIters];
+#pragma unroll
+                for (int i = 0; i < kFirstIters; ++i)
+                    if (lane + 64 * i < npairs) F[i] = scalar_base(src + 64 * i)[(unsigned)lane];
+#pragma unroll
+                for (int i = 0; i < kFirstIters; ++i)
+                    if (lane + 64 * i < npairs) f_dst[i * kPairStep] = F[i];
+            } else {  // the window reaches outside the channel: every sample range-checked (kept small, not fast)
+#pragma unroll 1
+                for (int p = fresh(lane) & 63; p < npairs; p += 64)
+                    imgw[(qlo / G::kSeg) * kGroupPairs + p + (p >> 4)] =
+                        dvec2{sample_at(xc, hc, g_lo + 2 * p, n, ntaps), sample_at(xc, hc, g_lo + 2 * p + 1, n, ntaps)};
+            }
+            wave_fence();
+        }
+
+        const double* xn = xc + (unsigned long long)(c0 + 1) * kChunk;  // the body of the chunk after the current one
+        double* yk = yc + (unsigned long long)c0 * kChunk;
+        long long left = n - (long long)c0 * kChunk;                    // outputs of the channel from this chunk on
+        for (unsigned k = c0; k < c1; ++k, xn += kChunk, yk += kChunk, left -= kChunk) {
+            const bool have_next = k + 1 < c1;
+            const bool next_full = have_next && !negative(left - 2 * kChunk);  // the next body lies inside the channel
+            dvec2 R[kBodyIters];
+            if (next_full) {
+#pragma unroll
+                for (int i = 0; i < kBodyIters; ++i)
+                    R[i] = stream_load(scalar_base(reinterpret_cast<const dvec2*>(xn) + 64 * i) + (unsigned)lane);
+            }
+            // The first sample vectors and the image's tail (the next chunk's halo) are asked for before the finished
+            // chunk's stores wait for its values: everything below up to the first matrix instruction is then one
+            // LDS round trip.
+            double w[RB];
+#pragma unroll
+            for (int j = 1; j < RB; ++j) w[j] = w_home[4 * (RB - j)];
+            w[0] = w_home[0];
+            const double* wp = w_home - G::kPadStep;
+            const double* ap = a_home;
+            double a_now = ap[0];
+            dvec2 Tl[kHaloIters];
+            if (have_next) {
+#pragma unroll
+                for (int i = 0; i < kHaloIters; ++i)
+                    if (lane + 64 * i < hpairs) Tl[i] = t_src[64 * i];
+            }
+            if (stores_due) store_chunk();
+            stores_due = false;
+#if M4W_PRIO == 1
+            __builtin_amdgcn_s_setprio(0);
+#elif M4W_PRIO == 2
+            switch ((prio_cnt++ + prio_slot) & 3) {
+                case 0: __builtin_amdgcn_s_setprio(0); break;
+                case 1: __builtin_amdgcn_s_setprio(1); break;
+                case 2: __builtin_amdgcn_s_setprio(2); break;
+                default: __builtin_amdgcn_s_setprio(3); break;
+            }
+#endif
+
+            // ---- products (the loop of fir_f64_mfma4_kernel, on this wave's image) ----
+#ifdef DSPX_M4W_TIMING
+            const unsigned long long ta = stamp();
+            if (t_last) t_rest += ta - t_last;
+#endif
+            {
+                int el = 0;
+                // `first`: the chunk's first step starts its sums from zero (no separate clearing of the accumulators)
+                auto group = [&](auto first) __attribute__((always_inline)) {
+#pragma unroll
+                    for (int u = 0; u < RB; ++u) {
+                        const double a = a_now;
+                        a_now = ap[4 * (u + 1)];
+#pragma unroll
+                        for (int rb = RB - 1; rb >= 0; --rb) {
+                            acc[rb] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, w[(u - rb + RB) % RB], (first.value && u == 0) ? 0.0 : acc[rb], 0, 0, 0);
+                            if (rb == RB - 1) w[(u + 1) % RB] = wp[G::kSeg - 4 * (u + 1)];
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    el += RB, wp -= G::kPadStep, ap += 4 * RB;
+                };
+                if (steps >= RB) {
+                    group(std::true_type{});
+                } else {
+#pragma unroll
+                    for (int rb = 0; rb < RB; ++rb) acc[rb] = 0.0;
+                }
+                while (el + RB <= steps) group(std::false_type{});
+                if (el < steps) {
+                    const int rem = steps - el;
+#pragma unroll
+                    for (int u = 0; u < RB - 1; ++u) {
+                        if (u < rem) {
+                            const double a = a_now;
+                            a_now = ap[4 * (u + 1)];
+#pragma unroll
+                            for (int rb = RB - 1; rb >= 0; --rb) {
+                                acc[rb] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, w[(u - rb + RB) % RB], acc[rb], 0, 0, 0);
+                                if (rb == RB - 1) w[(u + 1) % RB] = wp[G::kSeg - 4 * (u + 1)];
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                }
+            }
+#if M4W_PRIO == 1
+            __builtin_amdgcn_s_setprio(3);
+#endif
+#ifdef DSPX_M4W_TIMING
+            const unsigned long long tb = stamp();
+            t_prod += tb - ta;
+#endif
+
+            // ---- the exactness guard of fir_f64_mfma4_kernel: a wave with a non-finite accumulator sums its outputs
+            // again over the products the reference forms.  Eight independent compares joined on the scalar unit.
+            unsigned long long any_bad = 0;
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) any_bad |= __builtin_amdgcn_ballot_w64(not_finite(acc[rb]));
+#ifdef DSPX_M4W_TIMING
+            {
+                unsigned long long tc;
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tc) : "s"(any_bad) : "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                t_probe += tc - tb;
+                t_last = tc;
+                if (++n_chunks == 64) t_64 = tc;
+            }
+#endif
+            wave_fence();
+            // The whole image is dead now (its tail is in Tl): the halo of the next chunk goes to its place, the
+            // results pass through the body's place, and the next body follows them there.  A wave's LDS instructions
+            // execute in order, so none of these waits for another.
+            if (have_next) {
+#pragma unroll
+                for (int i = 0; i < kHaloIters; ++i)
+                    if (lane + 64 * i < hpairs) t_dst[64 * i] = Tl[i];
+            }
+            if (any_bad != 0) {
+                const long long pos = (long long)k * kChunk;
+#pragma unroll 1
+                for (int q = fresh(lane) & 63; q < kChunk; q += 64) {
+                    double sum = 0.0;
+                    for (int j = 0; j < ntaps; ++j) {
+                        const long long g = pos + q - j;
+                        if (g >= 0 && g < n)
+                            sum = __builtin_fma(taps[j], xc[g], sum);
+                        else if (g < 0 && hc != nullptr && g >= -(long long)(ntaps - 1))
+                            sum = __builtin_fma(taps[j], hc[(ntaps - 1) + g], sum);
+                    }
+                    imgd[kHaloGroups * G::kPadStep + q + (q >> G::kShift)] = sum;
+                }
+            } else {
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) o_home[4 * rb] = acc[rb];
+            }
+            wave_fence();
+#pragma unroll
+            for (int j = 0; j < kStores; ++j) O[j] = g_home[j * kBackStep];
+            wave_fence();
+            if (have_next) {
+                if (next_full) {
+#pragma unroll
+                    for (int i = 0; i < kBodyIters; ++i) b_dst[i * kPairStep] = R[i];
+                } else {  // the channel ends inside the next chunk: zeros past its end
+                    const long long pos = (long long)(k + 1) * kChunk;
+#pragma unroll 1
+                    for (int p = fresh(lane) & 63; p < kChunk / 2; p += 64)
+                        imgw[kHaloGroups * kGroupPairs + p + (p >> 4)] =
+                            dvec2{sample_at(xc, hc, pos + 2 * p, n, ntaps), sample_at(xc, hc, pos + 2 * p + 1, n, ntaps)};
+                }
+            }
+            wave_fence();
+            pend_yt = yk;
+            pend_left = negative(left - kChunk) ? (int)left : kChunk;
+            stores_due = true;
+        }
+#ifdef M4W_DYN
+        run = run_next;
+#endif
+    }
+    if (stores_due) store_chunk();
+#ifdef DSPX_M4W_TIMING
+    {
+        const unsigned long long t_end = stamp();
+        const unsigned gw = blockIdx.x * (kBlock / 64) + wave;
+        if (lane == 0 && gw < 8192) {
+            unsigned long long* o = g_m4w_timing + 16 * gw;
+            o[0] = t_prod, o[1] = t_probe, o[2] = t_rest, o[3] = n_chunks, o[4] = t_begin, o[5] = t_end;
+            o[6] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4)                     // HW_ID
+                   | ((unsigned long long)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 15) << 32);  // XCC_ID
+            o[7] = __builtin_amdgcn_s_memrealtime() - r_begin;
+            o[8] = t_64;
+        }
+    }
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------
 // lfilter<float> (reference dsp.hpp:361-364 with T = float): the sum is a float, and every product is formed in the
 // type the operands promote to -- double for containers of double, float for containers of float -- converted to
 // float and added, taps ascending.  TIN is that operand type.  Separately rounded operations in exactly the
@@ -901,6 +1259,47 @@ static void launch_mfma_variant(const double* taps, const double* x, const doubl
     const dim3 grid(8 * std::max(per_xcd, 1u)), block(kBlock);
     const bool single = !BANK && shape.ntaps > 0 && (shape.ntaps + 2) / 4 + 1 <= G::kStageSteps;  // one window per tile
     if constexpr (!BANK) {
+        const int wave_form = [] { const char* e = std::getenv("DSPX_M4W"); return e ? atoi(e) : 0; }();
+        if (single && vec2 && wave_form) {
+            // runs of consecutive 512-output chunks, one wave each: about eight runs per wave when the input is
+            // large (so that the waves end together), never shorter than 32 chunks unless the input is small
+            constexpr unsigned kChunk = G::kWaveOut;
+            const unsigned resident = [] { const char* e = std::getenv("DSPX_M4W_RES"); return e ? (unsigned)atoi(e) : 4u; }();
+            const unsigned runs_per_wave = [] { const char* e = std::getenv("DSPX_M4W_RPW"); return e ? (unsigned)atoi(e) : 8u; }();
+            const unsigned min_run = [] { const char* e = std::getenv("DSPX_M4W_MINRUN"); return e ? (unsigned)atoi(e) : 32u; }();
+            const unsigned nchan = shape.total_tiles / shape.tiles_per_chan;
+            const unsigned long long cpc = ((unsigned long long)shape.n + kChunk - 1) / kChunk;
+            const unsigned long long total_chunks = cpc * nchan;
+            const unsigned long long max_waves = (unsigned long long)compute_units() * resident * (kBlock / 64);
+            unsigned long long want = (total_chunks + runs_per_wave * max_waves - 1) / (runs_per_wave * max_waves);
+            if (want < min_run) want = std::min<unsigned long long>(min_run, std::max<unsigned long long>(1, total_chunks / max_waves));
+            want = std::min(want, cpc);
+            FirRuns rn{};
+            rn.chunks_per_chan = (unsigned)cpc;
+            rn.runs_per_chan = (unsigned)((cpc + want - 1) / want);
+            rn.run_chunks = (unsigned)((cpc + rn.runs_per_chan - 1) / rn.runs_per_chan);
+            rn.runs_per_chan = (unsigned)((cpc + rn.run_chunks - 1) / rn.run_chunks);
+            const unsigned long long total_runs = (unsigned long long)nchan * rn.runs_per_chan;
+            if (total_runs < (1ull << 31)) {
+                rn.total_runs = (unsigned)total_runs;
+                FirShape d{};
+                set_divider(d, rn.runs_per_chan);
+                rn.div_magic = d.div_magic, rn.div_shift = d.div_shift;
+                const unsigned wgs = (unsigned)std::min<unsigned long long>((total_runs + kBlock / 64 - 1) / (kBlock / 64), max_waves / (kBlock / 64));
+#ifdef M4W_DYN
+                {
+                    void* ctr = nullptr;
+                    (void)hipGetSymbolAddress(&ctr, HIP_SYMBOL(g_m4w_counter));
+                    (void)hipMemsetAsync(ctr, 0, sizeof(unsigned), stream);
+                }
+#endif
+                if (resident >= 5)
+                    hipLaunchKernelGGL((fir_f64_mfma4w_kernel<5>), dim3(wgs), block, 0, stream, taps, x, hist, y, shape, rn);
+                else
+                    hipLaunchKernelGGL((fir_f64_mfma4w_kernel<4>), dim3(wgs), block, 0, stream, taps, x, hist, y, shape, rn);
+                return;
+            }
+        }
         if (single) {
             if (vec2)
                 hipLaunchKernelGGL((fir_f64_mfma4_kernel<kMatrixOB, true, false, true>), grid, block, 0, stream, taps, x, hist, y, bank, shape);
@@ -1008,4 +1407,10 @@ hipError_t launch_checksum(const double* yv, unsigned long long n, unsigned long
 }
 
 }  // namespace dspx
+
+#ifdef DSPX_M4W_TIMING
+extern "C" __attribute__((visibility("default"))) int dspx_debug_m4w_timing(unsigned long long* out, size_t count) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(dspx::g_m4w_timing), count * sizeof(unsigned long long));
+}
+#endif
 

@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Development check: the wave-autonomous matrix kernel (DSPX_M4W=1) against the workgroup-tiled one, bit for bit,
+and against the oracle, over shapes that exercise run starts, channel ends, history and non-finite data."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+import dsp_amd
+from oracle.pyoracle import Oracle
+
+orc = Oracle()
+bad = 0
+rng = np.random.default_rng(7)
+cases = [(1, 512, 101), (1, 513, 101), (3, 5000, 255), (2, 100, 63), (1, 1 << 16, 281), (5, 70001, 57), (64, 1 << 14, 128),
+         (1, 1 << 20, 101), (7, 33333, 200), (1, 1, 56), (2, 511, 255), (300, 2048, 96), (1, (1 << 18) + 3, 77)]
+for minrun in ("32", "1", "3"):
+    os.environ["DSPX_M4W_MINRUN"] = minrun
+    for nchan, n, nt in cases:
+        taps_h = dsp_amd.firwin(nt, 0.25)
+        taps = torch.from_numpy(taps_h).cuda()
+        xh = rng.uniform(-1, 1, (nchan, n))
+        x = torch.from_numpy(xh).cuda()
+        for with_hist in (False, True):
+            hist = None
+            if with_hist:
+                hh = rng.uniform(-1, 1, (nchan, nt - 1))
+                hist = torch.from_numpy(hh).cuda()
+            os.environ["DSPX_M4W"] = "0"
+            y0 = dsp_amd.fir_device(taps, x, hist=hist, mfma=True).cpu().numpy()
+            os.environ["DSPX_M4W"] = "1"
+            y1 = dsp_amd.fir_device(taps, x, hist=hist, mfma=True).cpu().numpy()
+            same = np.array_equal(y0.view(np.uint64), y1.view(np.uint64))
+            err = 0.0
+            if nchan * n <= 1 << 18:
+                for c in range(min(nchan, 3)):
+                    xin = np.concatenate([hh[c], xh[c]]) if with_hist else xh[c]
+                    ref = orc.lfilter(taps_h, [1.0], xin)[-n:] if with_hist else orc.lfilter(taps_h, [1.0], xin)
+                    err = max(err, float(np.max(np.abs(ref - y1[c])) / max(np.max(np.abs(ref)), 1e-300)))
+            ok = same and err < 1e-12
+            bad += not ok
+            print(f"minrun={minrun} nchan={nchan} n={n} taps={nt} hist={with_hist}: bits_equal={same} err_vs_oracle={err:.2e} {'ok' if ok else 'FAIL'}", flush=True)
+# non-finite samples and taps
+os.environ["DSPX_M4W_MINRUN"] = "4"
+for nt in (101, 255):
+    taps_h = dsp_amd.firwin(nt, 0.25)
+    xh = rng.uniform(-1, 1, (2, 20000))
+    xh[0, 3000] = np.inf
+    xh[1, 12345] = np.nan
+    xh[1, 0] = -np.inf
+    th = taps_h.copy()
+    for tcase in ("finite", "inf_tap"):
+        if tcase == "inf_tap":
+            th[5] = np.inf
+        taps = torch.from_numpy(th).cuda()
+        x = torch.from_numpy(xh).cuda()
+        os.environ["DSPX_M4W"] = "0"
+        y0 = dsp_amd.fir_device(taps, x, mfma=True).cpu().numpy()
+        os.environ["DSPX_M4W"] = "1"
+        y1 = dsp_amd.fir_device(taps, x, mfma=True).cpu().numpy()
+        same = np.array_equal(y0.view(np.uint64), y1.view(np.uint64))
+        nanmap = all(np.array_equal(np.isfinite(orc.lfilter(th, [1.0], xh[c])), np.isfinite(y1[c])) for c in range(2))
+        bad += not (same and nanmap)
+        print(f"non-finite taps={nt} {tcase}: bits_equal={same} finite_map_equals_oracle={nanmap}", flush=True)
+print("FAILURES:", bad)
+sys.exit(1 if bad else 0)
