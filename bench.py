@@ -8,10 +8,14 @@ synthetic input that already sits in HBM.  The default workload is the configura
 headline metric is quoted on: 4096 channels x 2^20 samples, 255-tap firwin(255, 0.25).
 With N > 1 there is one process (rank) per GPU: either started by torch.distributed.run, or, when
 no launcher set WORLD_SIZE, by this script itself, which then only spawns the N ranks, forwards rank
-0's JSON line and returns the worst exit code (it never touches a GPU).  Every rank filters its own
-batch of that size (weak scaling; channels are independent, so there is no data-path collective);
-`--scaling strong` shards the 4096 channels over the ranks instead.  After the timed region the ranks
-all-gather a small slice of their results over RCCL (reported apart as `allgather`, never part of `value`).
+0's JSON line and returns the worst exit code (it never touches a GPU).  By default the named workload
+is sharded over the ranks (strong scaling: contiguous channel ranges, or, for a single stream, contiguous
+segments with ntaps-1 samples of history; channels and segments are independent, so there is no
+data-path collective) and `output_checksum` -- the position-dependent checksum of the whole output, summed
+over the ranks -- must be the same for every N.  A short loop in which every rank filters a whole batch of
+its own is reported beside it as `weak` (`--scaling weak` makes that the headline instead).  After the
+timed region the ranks all-gather a small slice of their results over RCCL (reported apart as `allgather`,
+never part of `value`).
 
 Rank 0 prints ONE JSON line with the metric, the roofline of the FIR kernel (per-launch HIP
 events on the launch stream) and, at N = 1, the CPU baseline (the reference's own single-threaded
@@ -57,7 +61,11 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="batched255", choices=sorted(WORKLOADS) + ["cwt65", "iir_biquad"])
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--scaling", default=None, choices=["weak", "strong"],
+                    help="N > 1 only.  strong (the default): the workload the metric names is sharded over the ranks "
+                         "(channel ranges, or segments with history for a single stream), and a short weak-scaling loop "
+                         "is reported beside it; weak: every rank filters a whole batch of its own")
+    ap.add_argument("--no-weak", action="store_true", help="with strong scaling: skip the weak-scaling sub-record")
     ap.add_argument("--exact", action="store_true", help="DSPX_FIR_EXACT arithmetic (separate mul/add)")
     ap.add_argument("--vector", action="store_true", help="force the vector-pipe kernel (DSPX_FIR_VECTOR)")
     ap.add_argument("--allgather", action="store_true",
@@ -428,23 +436,48 @@ def small_allgather(dsp_amd, dist, torch, y, rank, world, fence, on_gpu: bool):
         recv = 8.0 * rows * n * (world - 1)
         c_abi = None
         if on_gpu:   # the same exchange through the library's own entry point (dspx_allgather_f64_dev over its RCCL communicator)
+            # Every step that can fail on one rank alone is followed by an agreement (all-reduce MIN of an ok flag), so
+            # that the ranks skip the rest TOGETHER: a rank that left early would leave the others in a collective.
+            def agreed(ok: bool) -> bool:
+                flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=mine.device)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                return bool(int(flag[0]))
+
+            ident, err = None, None
             try:
-                box = [dsp_amd.Comm.unique_id() if rank == 0 else None]
-                dist.broadcast_object_list(box, src=0)
-                comm = dsp_amd.Comm(box[0], world, rank)
-                full2 = comm.allgather(mine_dev)          # warm-up
-                fence()
-                t0 = time.perf_counter()
-                full2 = comm.allgather(mine_dev, out=full2)
-                fence()
-                ms2 = (time.perf_counter() - t0) * 1e3
-                same = bool(torch.equal(full2, full))
-                comm.close()
-                t2 = torch.tensor([ms2, 0.0 if same else 1.0], dtype=torch.float64, device=mine.device)
-                dist.all_reduce(t2, op=dist.ReduceOp.MAX)
-                c_abi = {"ms": float(t2[0]), "GB/s_per_gpu": recv / float(t2[0]) / 1e6, "equals_torch_gather": float(t2[1]) == 0.0}
+                if rank == 0:
+                    ident = dsp_amd.Comm.unique_id()
+                else:
+                    dsp_amd.lib()   # the library (and its RCCL binding) must at least load here too
             except Exception as e:  # noqa: BLE001
-                c_abi = {"error": f"{type(e).__name__}: {e}"}
+                err = f"{type(e).__name__}: {e}"
+            if not agreed(err is None):
+                c_abi = {"error": err or "another rank could not reach the library's RCCL binding", "verified": False}
+            else:
+                box = [ident]
+                dist.broadcast_object_list(box, src=0)
+                comm = None
+                try:
+                    comm = dsp_amd.Comm(box[0], world, rank)
+                except Exception as e:  # noqa: BLE001
+                    err = f"{type(e).__name__}: {e}"
+                if not agreed(comm is not None):
+                    if comm is not None:
+                        comm.close()
+                    c_abi = {"error": err or "another rank could not create its communicator", "verified": False}
+                else:
+                    full2 = comm.allgather(mine_dev)          # warm-up
+                    fence()
+                    t0 = time.perf_counter()
+                    full2 = comm.allgather(mine_dev, out=full2)
+                    fence()
+                    ms2 = (time.perf_counter() - t0) * 1e3
+                    same = bool(torch.equal(full2, full))
+                    comm.close()
+                    t2 = torch.tensor([ms2, 0.0 if same else 1.0], dtype=torch.float64, device=mine.device)
+                    dist.all_reduce(t2, op=dist.ReduceOp.MAX)
+                    c_abi = {"ms": float(t2[0]), "GB/s_per_gpu": recv / float(t2[0]) / 1e6,
+                             "equals_torch_gather": float(t2[1]) == 0.0, "verified": float(t2[1]) == 0.0}
         return {"ms": float(t[0]), "rows_per_rank": rows, "bytes_received_per_gpu": recv, "dspx_allgather_f64_dev": c_abi,
                 "GB/s_per_gpu": recv / float(t[0]) / 1e6, "matches_per_rank_checksums": float(t[1]) == 0.0,
                 "transport": "RCCL (nccl backend), device buffers" if on_gpu else "rehearsal backend, host copies",
@@ -501,10 +534,12 @@ def main() -> None:
             dist.destroy_process_group()
         return
 
+    # N > 1 measures the workload the metric names, sharded over the ranks, unless --scaling weak asks otherwise
+    args.scaling = args.scaling or ("strong" if world > 1 else "weak")
     _, n, numtaps, cutoff, desc = WORKLOADS[args.workload]
     taps_h = dsp_amd.firwin(numtaps, cutoff)
     taps = torch.from_numpy(taps_h).to(dev)
-    hist = None
+    hist = buf = None
     segments = args.scaling == "strong" and world > 1 and WORKLOADS[args.workload][0] < world
     if segments:
         # fewer streams than GPUs: every rank filters a contiguous segment of every stream, with the
@@ -569,10 +604,45 @@ def main() -> None:
         gather_ms = (time.perf_counter() - t0) * 1e3
         del full
 
+    # The position-dependent checksum of this rank's outputs at their place in the whole output, summed over the
+    # ranks modulo 2^64: a sharding never changes an output's arithmetic, so with strong scaling the sum is the
+    # same for every N (32-bit halves are summed apart so that no signed 64-bit sum can overflow).
+    if segments:
+        own = sum(dsp_amd.checksum(y[c], c * n + lo) for c in range(nchan)) % (1 << 64)
+    else:
+        own = dsp_amd.checksum(y, chan0 * n)
+    halves = torch.tensor([own & 0xffffffff, own >> 32], dtype=torch.int64, device=red_dev)
+    if world > 1:
+        dist.all_reduce(halves)
+    output_checksum = (int(halves[0]) + (int(halves[1]) << 32)) % (1 << 64)
+
     t = torch.tensor([dt, float(np.mean(kern_ms)), gather_ms], dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt_max, kern_ms_max, gather_ms = float(t[0]), float(t[1]), float(t[2])
+
+    # Weak scaling beside the strong headline: every rank filters a whole batch of its own for a few steps.
+    weak = None
+    if world > 1 and args.scaling == "strong" and not args.no_weak:
+        nchan_total = WORKLOADS[args.workload][0]
+        del x, y, hist, buf
+        torch.cuda.empty_cache()
+        xw = torch.empty((nchan_total, n), dtype=torch.float64, device=dev)
+        yw = torch.empty_like(xw)
+        dsp_amd.fill_splitmix(xw, dsp_amd.SEED, rank * nchan_total * n)
+        wsteps = max(1, min(args.steps, 5))
+        dsp_amd.fir_device(taps, xw, out=yw, exact=args.exact, mfma=False if args.vector else None)   # warm-up
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(wsteps):
+            dsp_amd.fir_device(taps, xw, out=yw, exact=args.exact, mfma=False if args.vector else None)
+        fence()
+        tw = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+        weak = {"value": world * nchan_total * n * wsteps / float(tw[0]) / 1e9, "unit": "GS/s", "steps": wsteps, "warmup": 1,
+                "ms_per_step": float(tw[0]) / wsteps * 1e3, "nchan_per_gpu": nchan_total,
+                "note": "every rank filters a whole batch of the named shape (its own data); same timing rules as value"}
+        del xw, yw
 
     if rank == 0:
         matrix = not args.exact and not args.vector and numtaps >= dsp_amd.MATRIX_PIPE_MIN_TAPS
@@ -617,7 +687,13 @@ def main() -> None:
                                                              else "independent batch per GPU")},
             "roofline": primary,
             "roofline_other": secondary,
+            "output_checksum": f"0x{output_checksum:016x}",
         }
+        if args.scaling == "strong" or world == 1:
+            out["output_checksum_note"] = ("checksum of the whole output of the named workload (each rank's shard at its "
+                                           "global position, summed over ranks mod 2^64): identical for every --gpus N")
+        if weak is not None:
+            out["weak"] = weak
         if gather_small is not None:
             out["allgather"] = gather_small
         if gather_ms > 0.0:

@@ -16,6 +16,7 @@ DSPX_FIR_FMA = 0
 DSPX_FIR_EXACT = 1
 DSPX_FIR_MFMA = 2
 DSPX_FIR_VECTOR = 4
+DSPX_FIR_TILED = 8
 
 class Piece(C.Structure):
     _fields_ = [("device", C.c_int), ("chan", C.c_size_t), ("nchan", C.c_size_t), ("start", C.c_size_t),

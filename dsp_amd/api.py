@@ -11,7 +11,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import DSPX_FIR_EXACT, DSPX_FIR_FMA, DSPX_FIR_MFMA, DSPX_FIR_VECTOR, check, lib
+from ._lib import DSPX_FIR_EXACT, DSPX_FIR_FMA, DSPX_FIR_MFMA, DSPX_FIR_TILED, DSPX_FIR_VECTOR, check, lib
 
 SEED = 0x44535046495236
 # Pipe selection of the default flags (mirrors kMatrixPipeMinTaps in csrc/dspx_common.h):
@@ -28,13 +28,16 @@ def release_staging() -> int:
     return int(lib().dspx_release_staging())
 
 
-def _flags(exact: bool, mfma=None) -> int:
-    """exact -> DSPX_FIR_EXACT; mfma: None = library's choice, True / False = force the matrix / vector pipe."""
+def _flags(exact: bool, mfma=None, tiled: bool = False) -> int:
+    """exact -> DSPX_FIR_EXACT; mfma: None = library's choice, True / False = force the matrix / vector pipe;
+    tiled -> DSPX_FIR_TILED (the workgroup-tiled form of the matrix-pipe kernel, for comparison measurements)."""
     f = DSPX_FIR_EXACT if exact else DSPX_FIR_FMA
     if mfma is True:
         f |= DSPX_FIR_MFMA
     elif mfma is False:
         f |= DSPX_FIR_VECTOR
+    if tiled:
+        f |= DSPX_FIR_TILED
     return f
 
 
@@ -281,7 +284,7 @@ def _stream_ptr():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-def fir_device(taps, x, out=None, hist=None, exact: bool = False, mfma=None):
+def fir_device(taps, x, out=None, hist=None, exact: bool = False, mfma=None, tiled: bool = False):
     """Filters a float64 CUDA tensor x of shape (n,) or (channels, n) with device taps.
     `hist`, if given, has shape (..., ntaps-1): the samples preceding x along the last axis."""
     import torch
@@ -300,7 +303,7 @@ def fir_device(taps, x, out=None, hist=None, exact: bool = False, mfma=None):
         assert h2.stride(1) == 1 or h2.shape[1] <= 1
         hptr, hstride = h2.data_ptr(), h2.stride(0)
     check(lib().dspx_fir_f64_dev(taps.data_ptr(), taps.numel(), x2.data_ptr(), x2.stride(0), hptr, hstride,
-                                 o2.data_ptr(), o2.stride(0), x2.shape[0], x2.shape[1], _flags(exact, mfma),
+                                 o2.data_ptr(), o2.stride(0), x2.shape[0], x2.shape[1], _flags(exact, mfma, tiled),
                                  _stream_ptr()))
     return out.reshape(x.shape) if out.dim() != x.dim() else out
 

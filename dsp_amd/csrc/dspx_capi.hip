@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -24,6 +25,10 @@
 namespace dspx {
 
 thread_local std::string g_last_error;
+
+static std::atomic<int> g_alias_devices{0};
+bool devices_aliased() { return g_alias_devices.load(std::memory_order_relaxed) != 0; }
+int g_alias_devices_exchange(bool on) { return g_alias_devices.exchange(on ? 1 : 0); }
 
 int fail(int code, const char* fmt, ...) {
     char buf[512];
@@ -76,7 +81,7 @@ int launch_dev(const double* d_taps, size_t ntaps, const double* d_x, size_t x_s
         if (mfma)
             DSPX_HIP(dspx::launch_fir_mfma_f64(d_taps, d_x + c0 * x_stride,
                                                d_hist ? d_hist + c0 * hist_stride : nullptr, d_y + c0 * y_stride, s,
-                                               vec2, stream));
+                                               vec2, (flags & DSPX_FIR_TILED) != 0, stream));
         else
             DSPX_HIP(dspx::launch_fir_f64(d_taps, d_x + c0 * x_stride, d_hist ? d_hist + c0 * hist_stride : nullptr,
                                           d_y + c0 * y_stride, s, (flags & DSPX_FIR_EXACT) != 0, vec2, stream));
@@ -587,7 +592,8 @@ int host_path_body(const double* taps, size_t ntaps, const double* hist0, const 
         return run_device(cur, taps, ntaps, hist0, x, y, stride, pieces, flags, 4, tail);
     }
     int G = ngpus == 0 ? ndev : ngpus;
-    if (G > dspx::logical_device_limit(ndev))
+    const bool aliased = dspx::devices_aliased();  // read once, here
+    if (G > dspx::logical_device_limit(aliased, ndev))
         return fail(DSPX_ERR_INVALID, "ngpus (%d) exceeds visible devices (%d)", G, ndev);
     // a recursive filter's state is a serial dependence along a channel: such filters shard by channels only
     if (tail.order && nchan < (size_t)G) G = (int)nchan;
@@ -599,7 +605,7 @@ int host_path_body(const double* taps, size_t ntaps, const double* hist0, const 
         for (int g = 0; g < G; ++g)
             workers.threads.emplace_back([&, g] {
                 rcs[g] = dspx::guarded([&] {
-                    return run_device(dspx::physical_device(g, ndev), taps, ntaps, hist0, x, y, stride, plan[g], flags,
+                    return run_device(dspx::physical_device(aliased, g, ndev), taps, ntaps, hist0, x, y, stride, plan[g], flags,
                                       G > 2 ? 1 : 2, tail);
                 });
                 if (rcs[g] != DSPX_OK) msgs[g] = g_last_error;
@@ -1003,3 +1009,8 @@ int dspx_checksum_f64_dev(const double* d_y, size_t n, uint64_t offset, uint64_t
 }
 
 }  // extern "C"
+
+// Test hook, deliberately absent from include/dspx.h (see dspx_common.h): logical devices mapped onto the GPUs that exist.
+extern "C" DSPX_API int dspx_test_alias_devices(int enable) {
+    return dspx::g_alias_devices_exchange(enable != 0);
+}

@@ -28,7 +28,7 @@ constexpr unsigned long long kMaxGrid = (1ull << 24) - 1;
 constexpr size_t kMatrixPipeMinTaps = 56;
 
 inline int check_flags(unsigned flags) {
-    if (flags & ~(DSPX_FIR_EXACT | DSPX_FIR_MFMA | DSPX_FIR_VECTOR))
+    if (flags & ~(DSPX_FIR_EXACT | DSPX_FIR_MFMA | DSPX_FIR_VECTOR | DSPX_FIR_TILED))
         return fail(DSPX_ERR_INVALID, "unknown flag bits 0x%x", flags);
     if ((flags & DSPX_FIR_MFMA) && (flags & DSPX_FIR_VECTOR))
         return fail(DSPX_ERR_INVALID, "DSPX_FIR_MFMA and DSPX_FIR_VECTOR exclude each other");
@@ -50,17 +50,18 @@ int download_rows(int device, const double* d_src, size_t src_pitch, size_t rows
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
-// Test knob for machines with fewer GPUs than a sharding is meant for: with DSPX_ALIAS_DEVICES=1 in the
-// environment the multi-device entry points accept any ngpus up to kMaxAliasedDevices and run logical device g
-// on physical device g % (visible devices), each logical device with its own thread, staging engine and plan,
-// exactly as on a machine that has them.  Results do not depend on it (nor on ngpus at all).
+// Test hook for machines with fewer GPUs than a sharding is meant for.  It is NOT part of the C ABI (include/dspx.h
+// does not declare it) and nothing in the environment can switch it on: a test harness calls
+//     extern "C" int dspx_test_alias_devices(int enable);   // returns the previous setting
+// after which the multi-device entry points accept any ngpus up to kMaxAliasedDevices and run logical device g on
+// physical device g % (visible devices), each logical device with its own thread, staging engine and plan, exactly
+// as on a machine that has them.  Results do not depend on it (nor on ngpus at all).  An entry point reads the
+// setting once, in the calling thread, and hands it to its workers.
 constexpr int kMaxAliasedDevices = 16;
-inline bool devices_aliased() {
-    const char* e = std::getenv("DSPX_ALIAS_DEVICES");
-    return e && e[0] == '1' && e[1] == '\0';
-}
-inline int logical_device_limit(int visible) { return devices_aliased() ? kMaxAliasedDevices : visible; }
-inline int physical_device(int logical, int visible) { return devices_aliased() && visible > 0 ? logical % visible : logical; }
+bool devices_aliased();  // the current setting (dspx_capi.hip)
+int g_alias_devices_exchange(bool on);
+inline int logical_device_limit(bool aliased, int visible) { return aliased ? kMaxAliasedDevices : visible; }
+inline int physical_device(bool aliased, int logical, int visible) { return aliased && visible > 0 ? logical % visible : logical; }
 
 // Threads that are joined when the owner goes out of scope, whichever way it leaves.
 struct Joiner {

@@ -263,7 +263,8 @@ int cwt_host(const double* signal, size_t n, const double* scales, size_t nscale
         return run_cwt_device(cur, t, psi, all, signal, n, result, flags);
     }
     const int G = ngpus == 0 ? ndev : ngpus;
-    if (G > dspx::logical_device_limit(ndev))
+    const bool aliased = dspx::devices_aliased();  // read once, here
+    if (G > dspx::logical_device_limit(aliased, ndev))
         return fail(DSPX_ERR_INVALID, "ngpus (%d) exceeds visible devices (%d)", G, ndev);
     const std::vector<int> dev = assign_rows(t, G);
     std::vector<std::vector<size_t>> picks(G);
@@ -275,7 +276,7 @@ int cwt_host(const double* signal, size_t n, const double* scales, size_t nscale
         for (int g = 0; g < G; ++g)
             workers.threads.emplace_back([&, g] {
                 rcs[g] = dspx::guarded([&] {
-                    return run_cwt_device(dspx::physical_device(g, ndev), t, psi, picks[g], signal, n, result, flags);
+                    return run_cwt_device(dspx::physical_device(aliased, g, ndev), t, psi, picks[g], signal, n, result, flags);
                 });
                 if (rcs[g] != DSPX_OK) msgs[g] = dspx::g_last_error;
             });

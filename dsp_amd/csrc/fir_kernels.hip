@@ -794,11 +794,10 @@ __global__ __launch_bounds__(kBlock, OB == 4 ? 2 : 4) void fir_f64_mfma4_kernel(
 //     workgroup-tiled kernel.
 // Per chunk a wave issues, besides its matrix instructions, 4 loads, 8 stores, 26 LDS instructions and about two
 // dozen vector instructions, and waits for nobody but itself.
-#ifndef M4W_PRIO
-#define M4W_PRIO 0
-#endif
-#ifdef M4W_DYN
-__device__ unsigned g_m4w_counter[1];
+#ifndef M4W_ABLATE
+// Development builds only (tools/build_variant.sh): 2 leaves out the result stores, 16 the sample loads of the steady
+// state, to time the kernel without that memory traffic.  The results of such a build are wrong.
+#define M4W_ABLATE 0
 #endif
 struct FirRuns {
     unsigned long long div_magic;  // run / runs_per_chan == (run * div_magic) >> div_shift
@@ -905,10 +904,6 @@ __global__ __launch_bounds__(kBlock, RESIDENT) void fir_f64_mfma4w_kernel(const 
     };
 
     double acc[RB];
-#if M4W_PRIO == 2
-    unsigned prio_cnt = 0;
-    const unsigned prio_slot = __builtin_amdgcn_s_getreg((3 << 11) | 4);  // HW_ID.wave_id
-#endif
 
     const unsigned nwaves = gridDim.x * (kBlock / 64);
 #ifdef DSPX_M4W_TIMING
@@ -916,16 +911,7 @@ __global__ __launch_bounds__(kBlock, RESIDENT) void fir_f64_mfma4w_kernel(const 
     const unsigned long long t_begin = stamp();
     const unsigned long long r_begin = __builtin_amdgcn_s_memrealtime();
 #endif
-#ifdef M4W_DYN
-    // development variant: runs handed out by a counter (zeroed by the host before the launch), first come first served
-    unsigned run = blockIdx.x * (kBlock / 64) + wave;
-    for (; run < rn.total_runs;) {
-        unsigned nxt = 0;
-        if (lane == 0) nxt = atomicAdd(g_m4w_counter, 1u);
-        const unsigned run_next = nwaves + (unsigned)__builtin_amdgcn_readfirstlane((int)nxt);
-#else
     for (unsigned run = blockIdx.x * (kBlock / 64) + wave; run < rn.total_runs; run += nwaves) {
-#endif
         const unsigned chan = (unsigned)(((unsigned long long)run * rn.div_magic) >> rn.div_shift);
         const unsigned c0 = (run - chan * rn.runs_per_chan) * rn.run_chunks;
         const unsigned c1 = min(c0 + rn.run_chunks, rn.chunks_per_chan);
@@ -961,7 +947,7 @@ __global__ __launch_bounds__(kBlock, RESIDENT) void fir_f64_mfma4w_kernel(const 
         long long left = n - (long long)c0 * kChunk;                    // outputs of the channel from this chunk on
         for (unsigned k = c0; k < c1; ++k, xn += kChunk, yk += kChunk, left -= kChunk) {
             const bool have_next = k + 1 < c1;
-            const bool next_full = have_next && !negative(left - 2 * kChunk);  // the next body lies inside the channel
+            const bool next_full = have_next && !negative(left - 2 * kChunk) && !(M4W_ABLATE & 16);  // the next body lies inside the channel
             dvec2 R[kBodyIters];
             if (next_full) {
 #pragma unroll
@@ -984,18 +970,12 @@ __global__ __launch_bounds__(kBlock, RESIDENT) void fir_f64_mfma4w_kernel(const 
                 for (int i = 0; i < kHaloIters; ++i)
                     if (lane + 64 * i < hpairs) Tl[i] = t_src[64 * i];
             }
-            if (stores_due) store_chunk();
-            stores_due = false;
-#if M4W_PRIO == 1
-            __builtin_amdgcn_s_setprio(0);
-#elif M4W_PRIO == 2
-            switch ((prio_cnt++ + prio_slot) & 3) {
-                case 0: __builtin_amdgcn_s_setprio(0); break;
-                case 1: __builtin_amdgcn_s_setprio(1); break;
-                case 2: __builtin_amdgcn_s_setprio(2); break;
-                default: __builtin_amdgcn_s_setprio(3); break;
+            if (stores_due && !(M4W_ABLATE & 2)) store_chunk();
+            if ((M4W_ABLATE & 2) && stores_due) {
+#pragma unroll
+                for (int j = 0; j < kStores; ++j) asm volatile("" ::"v"(O[j]));
             }
-#endif
+            stores_due = false;
 
             // ---- products (the loop of fir_f64_mfma4_kernel, on this wave's image) ----
 #ifdef DSPX_M4W_TIMING
@@ -1043,9 +1023,6 @@ __global__ __launch_bounds__(kBlock, RESIDENT) void fir_f64_mfma4w_kernel(const 
                     }
                 }
             }
-#if M4W_PRIO == 1
-            __builtin_amdgcn_s_setprio(3);
-#endif
 #ifdef DSPX_M4W_TIMING
             const unsigned long long tb = stamp();
             t_prod += tb - ta;
@@ -1102,7 +1079,7 @@ __global__ __launch_bounds__(kBlock, RESIDENT) void fir_f64_mfma4w_kernel(const 
                 if (next_full) {
 #pragma unroll
                     for (int i = 0; i < kBodyIters; ++i) b_dst[i * kPairStep] = R[i];
-                } else {  // the channel ends inside the next chunk: zeros past its end
+                } else if (!(M4W_ABLATE & 16)) {  // the channel ends inside the next chunk: zeros past its end
                     const long long pos = (long long)(k + 1) * kChunk;
 #pragma unroll 1
                     for (int p = fresh(lane) & 63; p < kChunk / 2; p += 64)
@@ -1115,9 +1092,6 @@ __global__ __launch_bounds__(kBlock, RESIDENT) void fir_f64_mfma4w_kernel(const 
             pend_left = negative(left - kChunk) ? (int)left : kChunk;
             stores_due = true;
         }
-#ifdef M4W_DYN
-        run = run_next;
-#endif
     }
     if (stores_due) store_chunk();
 #ifdef DSPX_M4W_TIMING
@@ -1250,53 +1224,46 @@ static unsigned compute_units() {
     return cached[dev] = (unsigned)cus;
 }
 
+// Cuts `nchan` channels of `n` samples into runs of consecutive 512-output chunks for the wave-autonomous kernel: a
+// run never crosses a channel; with a large input there are about kRunsPerWave runs per resident wave, so that the
+// waves end together, and never fewer than kMinRun chunks per run unless the input is too small to occupy every
+// wave that way (a run's first window is fetched with its halo, the only samples read twice).
+static bool plan_runs(unsigned nchan, long long n, unsigned max_waves, FirRuns& rn) {
+    constexpr unsigned long long kChunk = M4Geo<kMatrixOB>::kWaveOut, kRunsPerWave = 8, kMinRun = 32;
+    const unsigned long long cpc = ((unsigned long long)n + kChunk - 1) / kChunk, total_chunks = cpc * nchan;
+    unsigned long long want = (total_chunks + kRunsPerWave * max_waves - 1) / (kRunsPerWave * max_waves);
+    if (want < kMinRun) want = std::min(kMinRun, std::max<unsigned long long>(1, total_chunks / max_waves));
+    want = std::min(want, cpc);
+    rn = FirRuns{};
+    rn.chunks_per_chan = (unsigned)cpc;
+    rn.runs_per_chan = (unsigned)((cpc + want - 1) / want);
+    rn.run_chunks = (unsigned)((cpc + rn.runs_per_chan - 1) / rn.runs_per_chan);
+    rn.runs_per_chan = (unsigned)((cpc + rn.run_chunks - 1) / rn.run_chunks);
+    const unsigned long long total_runs = (unsigned long long)nchan * rn.runs_per_chan;
+    if (cpc > 0x7fffffffull || total_runs >= (1ull << 31)) return false;  // (the divider below covers 31 bits)
+    rn.total_runs = (unsigned)total_runs;
+    FirShape d{};
+    set_divider(d, rn.runs_per_chan);
+    rn.div_magic = d.div_magic, rn.div_shift = d.div_shift;
+    return true;
+}
+
 template <bool BANK>
 static void launch_mfma_variant(const double* taps, const double* x, const double* hist, double* y, const BankRow* bank,
-                                const FirShape& shape, bool vec2, hipStream_t stream) {
+                                const FirShape& shape, bool vec2, bool tiled, hipStream_t stream) {
     // persistent workgroups: a few per CU, in multiples of 8 (one share per XCD), never more than there are tiles
     using G = M4Geo<kMatrixOB>;
     const unsigned per_xcd = std::min((shape.total_tiles + 7) / 8, compute_units() * G::kResident / 8);
     const dim3 grid(8 * std::max(per_xcd, 1u)), block(kBlock);
     const bool single = !BANK && shape.ntaps > 0 && (shape.ntaps + 2) / 4 + 1 <= G::kStageSteps;  // one window per tile
     if constexpr (!BANK) {
-        const int wave_form = [] { const char* e = std::getenv("DSPX_M4W"); return e ? atoi(e) : 0; }();
-        if (single && vec2 && wave_form) {
-            // runs of consecutive 512-output chunks, one wave each: about eight runs per wave when the input is
-            // large (so that the waves end together), never shorter than 32 chunks unless the input is small
-            constexpr unsigned kChunk = G::kWaveOut;
-            const unsigned resident = [] { const char* e = std::getenv("DSPX_M4W_RES"); return e ? (unsigned)atoi(e) : 4u; }();
-            const unsigned runs_per_wave = [] { const char* e = std::getenv("DSPX_M4W_RPW"); return e ? (unsigned)atoi(e) : 8u; }();
-            const unsigned min_run = [] { const char* e = std::getenv("DSPX_M4W_MINRUN"); return e ? (unsigned)atoi(e) : 32u; }();
-            const unsigned nchan = shape.total_tiles / shape.tiles_per_chan;
-            const unsigned long long cpc = ((unsigned long long)shape.n + kChunk - 1) / kChunk;
-            const unsigned long long total_chunks = cpc * nchan;
-            const unsigned long long max_waves = (unsigned long long)compute_units() * resident * (kBlock / 64);
-            unsigned long long want = (total_chunks + runs_per_wave * max_waves - 1) / (runs_per_wave * max_waves);
-            if (want < min_run) want = std::min<unsigned long long>(min_run, std::max<unsigned long long>(1, total_chunks / max_waves));
-            want = std::min(want, cpc);
-            FirRuns rn{};
-            rn.chunks_per_chan = (unsigned)cpc;
-            rn.runs_per_chan = (unsigned)((cpc + want - 1) / want);
-            rn.run_chunks = (unsigned)((cpc + rn.runs_per_chan - 1) / rn.runs_per_chan);
-            rn.runs_per_chan = (unsigned)((cpc + rn.run_chunks - 1) / rn.run_chunks);
-            const unsigned long long total_runs = (unsigned long long)nchan * rn.runs_per_chan;
-            if (total_runs < (1ull << 31)) {
-                rn.total_runs = (unsigned)total_runs;
-                FirShape d{};
-                set_divider(d, rn.runs_per_chan);
-                rn.div_magic = d.div_magic, rn.div_shift = d.div_shift;
-                const unsigned wgs = (unsigned)std::min<unsigned long long>((total_runs + kBlock / 64 - 1) / (kBlock / 64), max_waves / (kBlock / 64));
-#ifdef M4W_DYN
-                {
-                    void* ctr = nullptr;
-                    (void)hipGetSymbolAddress(&ctr, HIP_SYMBOL(g_m4w_counter));
-                    (void)hipMemsetAsync(ctr, 0, sizeof(unsigned), stream);
-                }
-#endif
-                if (resident >= 5)
-                    hipLaunchKernelGGL((fir_f64_mfma4w_kernel<5>), dim3(wgs), block, 0, stream, taps, x, hist, y, shape, rn);
-                else
-                    hipLaunchKernelGGL((fir_f64_mfma4w_kernel<4>), dim3(wgs), block, 0, stream, taps, x, hist, y, shape, rn);
+        if (single && vec2 && !tiled) {
+            constexpr unsigned kWaves = kBlock / 64, kResident = 4;
+            const unsigned max_waves = compute_units() * kResident * kWaves;
+            FirRuns rn;
+            if (plan_runs(shape.total_tiles / shape.tiles_per_chan, shape.n, max_waves, rn)) {
+                const unsigned wgs = std::min((rn.total_runs + kWaves - 1) / kWaves, max_waves / kWaves);
+                hipLaunchKernelGGL((fir_f64_mfma4w_kernel<kResident>), dim3(wgs), block, 0, stream, taps, x, hist, y, shape, rn);
                 return;
             }
         }
@@ -1315,16 +1282,16 @@ static void launch_mfma_variant(const double* taps, const double* x, const doubl
 }
 
 hipError_t launch_fir_mfma_f64(const double* taps, const double* x, const double* hist, double* y,
-                               const FirShape& shape, bool vec2, hipStream_t stream) {
+                               const FirShape& shape, bool vec2, bool tiled, hipStream_t stream) {
     if (shape.total_tiles == 0) return hipSuccess;
-    launch_mfma_variant<false>(taps, x, hist, y, nullptr, shape, vec2, stream);
+    launch_mfma_variant<false>(taps, x, hist, y, nullptr, shape, vec2, tiled, stream);
     return hipGetLastError();
 }
 
 hipError_t launch_fir_mfma_bank_f64(const double* taps, const BankRow* bank, const double* x, double* y,
                                     const FirShape& shape, bool vec2, hipStream_t stream) {
     if (shape.total_tiles == 0) return hipSuccess;
-    launch_mfma_variant<true>(taps, x, nullptr, y, bank, shape, vec2, stream);
+    launch_mfma_variant<true>(taps, x, nullptr, y, bank, shape, vec2, false, stream);
     return hipGetLastError();
 }
 

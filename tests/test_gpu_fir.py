@@ -370,3 +370,38 @@ def test_single_precision_reference_literals(dsp, oracle, literals):
     ref = oracle.lfilter_f32_from_f64(w2, x)
     got = dsp.lfilter_f32(w2, x)
     assert np.isfinite(ref[:40]).all() and np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+
+
+# ---- the two forms of the matrix-pipe kernel ----
+
+@pytest.mark.parametrize("nchan,n,ntaps", [(1, 513, 101), (3, 5000, 255), (2, 100, 63), (5, 70_001, 57), (300, 2048, 96),
+                                           (40, 500_003, 101), (3, (1 << 23) + 5, 255), (1, (1 << 25) + 1000, 63),
+                                           (130, 1 << 18, 160), (1, 1 << 20, 281)])
+def test_wave_autonomous_form_equals_workgroup_tiled_form(dsp, oracle, torch, nchan, n, ntaps):
+    """Filters of up to 281 taps over aligned buffers run the wave-autonomous form of the matrix-pipe kernel (every wave
+    walks a run of 512-output chunks and carries its halo in LDS); DSPX_FIR_TILED forces the workgroup-tiled form.
+    Same products in the same order: the same bits -- with and without history, for runs of one chunk (small inputs)
+    and of several (the large ones here), channels that end inside a chunk, and against the oracle on windows."""
+    taps_h = dsp.firwin(ntaps, 0.25)
+    taps = torch.from_numpy(taps_h).cuda()
+    x = torch.empty((nchan, n), dtype=torch.float64, device="cuda")
+    dsp.fill_splitmix(x, dsp.SEED, 11)
+    hist = torch.empty((nchan, ntaps - 1), dtype=torch.float64, device="cuda")
+    dsp.fill_splitmix(hist, dsp.SEED, 1 << 40)
+    for h in (None, hist):
+        wave = dsp.fir_device(taps, x, hist=h, mfma=True)
+        tiled = dsp.fir_device(taps, x, hist=h, mfma=True, tiled=True)
+        assert torch.equal(wave.view(torch.int64), tiled.view(torch.int64))
+        # windows against the oracle: the start, the end, and a stretch in the middle of the first and last channel
+        for c in {0, nchan - 1}:
+            xc = x[c].cpu().numpy()
+            lead = h[c].cpu().numpy() if h is not None else np.zeros(0)
+            for lo in {0, max(0, n // 2 - 3000), max(0, n - 6000)}:
+                hi = min(n, lo + 6000)
+                back = min(lo, ntaps - 1)
+                seg = np.concatenate([lead, xc[:hi]]) if lo < ntaps else xc[lo - back:hi]
+                ref = oracle.lfilter(taps_h, [1.0], seg)
+                ref = ref[len(lead) + lo:] if lo < ntaps else ref[back:]
+                if lo >= ntaps or h is not None or lo == 0:
+                    got = wave[c, lo:hi].cpu().numpy()
+                    assert scaled_err(got, ref[:hi - lo]) <= TOL, (c, lo)

@@ -1,8 +1,10 @@
 """The multi-device host sharder (dspx_fir_f64_multi, dspx_lfilter_f64_multi, dspx_cwt_f64_multi) with more than
 one logical device: a thread, a staging engine and a plan per device, all running at once.  On a one-GPU machine
-DSPX_ALIAS_DEVICES=1 maps the logical devices onto the GPU that is there (the code path is the same, only
-hipSetDevice's argument differs); the same checks run un-aliased when the machine has two GPUs or more.
+the library's test hook dspx_test_alias_devices (not part of include/dspx.h) maps the logical devices onto the GPU
+that is there (the code path is the same, only hipSetDevice's argument differs); the same checks run un-aliased
+when the machine has two GPUs or more.
 Results must be the same bits for every device count, and must meet the parity bar against the oracle."""
+import ctypes as C
 import os
 
 import numpy as np
@@ -31,19 +33,24 @@ def dsp():
 
 @pytest.fixture(params=["aliased", "physical"])
 def counts(request, dsp):
-    """Device counts to run with; sets / clears the aliasing knob around the test."""
-    old = os.environ.pop("DSPX_ALIAS_DEVICES", None)
+    """Device counts to run with; switches the library's aliasing test hook on and off around the test."""
+    hook = dsp.lib().dspx_test_alias_devices   # a test hook: exported, but not declared in include/dspx.h
+    hook.restype, hook.argtypes = C.c_int, [C.c_int]
     if request.param == "aliased":
-        os.environ["DSPX_ALIAS_DEVICES"] = "1"
-        yield COUNTS
+        old = hook(1)
+        try:
+            yield COUNTS
+        finally:
+            hook(old)
     else:
         have = dsp.device_count()
         if have < 2:
             pytest.skip("needs two GPUs or more")
-        yield tuple(g for g in COUNTS if g <= have)
-    os.environ.pop("DSPX_ALIAS_DEVICES", None)
-    if old is not None:
-        os.environ["DSPX_ALIAS_DEVICES"] = old
+        old = hook(0)
+        try:
+            yield tuple(g for g in COUNTS if g <= have)
+        finally:
+            hook(old)
 
 
 def lfilter_multi(dsp, b, x, ngpus, exact=False, mfma=None):
@@ -116,9 +123,12 @@ def test_wavelet_bank_shards_scales(dsp, oracle, counts):
 
 
 def test_device_count_beyond_the_machine_is_refused(dsp):
-    os.environ.pop("DSPX_ALIAS_DEVICES", None)
-    with pytest.raises(dsp.DspxError, match="exceeds visible devices"):
-        lfilter_multi(dsp, np.ones(3), np.ones(100), dsp.device_count() + 1)
+    os.environ["DSPX_ALIAS_DEVICES"] = "1"   # no environment variable can widen what ngpus means
+    try:
+        with pytest.raises(dsp.DspxError, match="exceeds visible devices"):
+            lfilter_multi(dsp, np.ones(3), np.ones(100), dsp.device_count() + 1)
+    finally:
+        os.environ.pop("DSPX_ALIAS_DEVICES", None)
 
 
 def test_recursive_channels_of_several_pieces_do_not_mix_states(dsp, oracle):
@@ -169,20 +179,35 @@ def test_bench_two_ranks_without_a_launcher():
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ)
-    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "DSPX_ALIAS_DEVICES"):
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     if torch.cuda.device_count() < 2:
         env.update(DSPX_BENCH_BACKEND="gloo", DSPX_BENCH_ONE_DEVICE="1")
-    for scaling in ("weak", "strong"):
-        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "small255",
-                            "--steps", "3", "--warmup", "1", "--scaling", scaling], env=env, capture_output=True,
-                           text=True, timeout=280)
+    def run(*extra):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1", *extra],
+                           env=env, capture_output=True, text=True, timeout=280)
         assert r.returncode == 0, r.stderr[-3000:]
         lines = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
         assert len(lines) == 1
-        out = lines[0]
-        assert out["n_gpus"] == 2 and out["ranks_seen"] == 2 and out["scaling"] == scaling and out["value"] > 0
-        assert out["allgather"].get("matches_per_rank_checksums") is True, out["allgather"]
+        return lines[0]
+
+    # one rank: the checksum of the whole output, which no sharding may change
+    single = {w: run("--gpus", "1", "--workload", w, "--no-cpu-baseline") for w in ("small255", "long4095")}
+    # two ranks, defaults: the named workload sharded (channel ranges), a weak-scaling loop beside it
+    out = run("--gpus", "2", "--workload", "small255")
+    assert out["n_gpus"] == 2 and out["ranks_seen"] == 2 and out["scaling"] == "strong" and out["value"] > 0
+    assert out["config"]["sharding"] == "channels" and out["config"]["nchan_per_gpu"] == 32
+    assert out["output_checksum"] == single["small255"]["output_checksum"]
+    assert out["weak"]["value"] > 0 and out["weak"]["nchan_per_gpu"] == 64
+    assert out["allgather"].get("matches_per_rank_checksums") is True, out["allgather"]
+    # a single stream is cut into segments with history: same checksum again
+    seg = run("--gpus", "2", "--workload", "long4095", "--no-weak")
+    assert seg["config"]["sharding"] == "segments with history" and seg["scaling"] == "strong"
+    assert seg["output_checksum"] == single["long4095"]["output_checksum"]
+    # weak scaling on request: every rank its own batch
+    weak = run("--gpus", "2", "--workload", "small255", "--scaling", "weak")
+    assert weak["scaling"] == "weak" and weak["config"]["nchan_per_gpu"] == 64 and "weak" not in weak
+    assert weak["allgather"].get("matches_per_rank_checksums") is True, weak["allgather"]
 
 
 def test_rccl_allgather_entry_point_single_rank(dsp):

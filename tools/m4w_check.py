@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Development check: the wave-autonomous matrix kernel (DSPX_M4W=1) against the workgroup-tiled one, bit for bit,
+"""Development check: the wave-autonomous matrix kernel against the workgroup-tiled one (DSPX_FIR_TILED), bit for bit,
 and against the oracle, over shapes that exercise run starts, channel ends, history and non-finite data."""
 import os
 import sys
@@ -15,9 +15,9 @@ orc = Oracle()
 bad = 0
 rng = np.random.default_rng(7)
 cases = [(1, 512, 101), (1, 513, 101), (3, 5000, 255), (2, 100, 63), (1, 1 << 16, 281), (5, 70001, 57), (64, 1 << 14, 128),
-         (1, 1 << 20, 101), (7, 33333, 200), (1, 1, 56), (2, 511, 255), (300, 2048, 96), (1, (1 << 18) + 3, 77)]
-for minrun in ("32", "1", "3"):
-    os.environ["DSPX_M4W_MINRUN"] = minrun
+         (1, 1 << 20, 101), (7, 33333, 200), (1, 1, 56), (2, 511, 255), (300, 2048, 96), (1, (1 << 18) + 3, 77),
+         (40, 500_003, 101), (3, (1 << 23) + 5, 255), (1, (1 << 26) + 1000, 63), (130, 1 << 18, 160)]
+for minrun in ("default",):
     for nchan, n, nt in cases:
         taps_h = dsp_amd.firwin(nt, 0.25)
         taps = torch.from_numpy(taps_h).cuda()
@@ -28,9 +28,7 @@ for minrun in ("32", "1", "3"):
             if with_hist:
                 hh = rng.uniform(-1, 1, (nchan, nt - 1))
                 hist = torch.from_numpy(hh).cuda()
-            os.environ["DSPX_M4W"] = "0"
-            y0 = dsp_amd.fir_device(taps, x, hist=hist, mfma=True).cpu().numpy()
-            os.environ["DSPX_M4W"] = "1"
+            y0 = dsp_amd.fir_device(taps, x, hist=hist, mfma=True, tiled=True).cpu().numpy()
             y1 = dsp_amd.fir_device(taps, x, hist=hist, mfma=True).cpu().numpy()
             same = np.array_equal(y0.view(np.uint64), y1.view(np.uint64))
             err = 0.0
@@ -43,7 +41,6 @@ for minrun in ("32", "1", "3"):
             bad += not ok
             print(f"minrun={minrun} nchan={nchan} n={n} taps={nt} hist={with_hist}: bits_equal={same} err_vs_oracle={err:.2e} {'ok' if ok else 'FAIL'}", flush=True)
 # non-finite samples and taps
-os.environ["DSPX_M4W_MINRUN"] = "4"
 for nt in (101, 255):
     taps_h = dsp_amd.firwin(nt, 0.25)
     xh = rng.uniform(-1, 1, (2, 20000))
@@ -56,9 +53,7 @@ for nt in (101, 255):
             th[5] = np.inf
         taps = torch.from_numpy(th).cuda()
         x = torch.from_numpy(xh).cuda()
-        os.environ["DSPX_M4W"] = "0"
-        y0 = dsp_amd.fir_device(taps, x, mfma=True).cpu().numpy()
-        os.environ["DSPX_M4W"] = "1"
+        y0 = dsp_amd.fir_device(taps, x, mfma=True, tiled=True).cpu().numpy()
         y1 = dsp_amd.fir_device(taps, x, mfma=True).cpu().numpy()
         same = np.array_equal(y0.view(np.uint64), y1.view(np.uint64))
         nanmap = all(np.array_equal(np.isfinite(orc.lfilter(th, [1.0], xh[c])), np.isfinite(y1[c])) for c in range(2))

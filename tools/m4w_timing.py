@@ -13,7 +13,6 @@ import dsp_amd
 from dsp_amd._lib import lib
 
 W = {"b160": (2048, 1 << 20, 160), "b96": (2048, 1 << 20, 96), "b255": (4096, 1 << 20, 255), "l101": (1, 1 << 28, 101), "b128": (2048, 1 << 20, 128), "b63": (1024, 1 << 20, 63)}
-os.environ.setdefault("DSPX_M4W", "1")
 for nm in sys.argv[1:] or ["l101"]:
     nchan, n, nt = W[nm]
     taps = torch.from_numpy(dsp_amd.firwin(nt, 0.25)).cuda()
