@@ -151,6 +151,8 @@ def lfilter_iir_device(b, a, x, out=None, xhist=None, yhist=None, exact: bool = 
     assert x2.is_cuda and x2.dtype == torch.float64 and x2.stride(1) == 1 and b.is_cuda and b.dtype == torch.float64
     nchan, n = x2.shape
     if out is None:
+        if noalloc:
+            raise ValueError("noalloc=True needs `out`: allocating the result here would defeat the call's purpose")
         out = torch.empty_like(x)
     o2 = out.reshape(1, -1) if out.dim() == 1 else out
     assert o2.shape == x2.shape and o2.stride(1) == 1 and o2.dtype == torch.float64
@@ -164,7 +166,7 @@ def lfilter_iir_device(b, a, x, out=None, xhist=None, yhist=None, exact: bool = 
 
     xh, xhs = hist_args(xhist, max(b.numel() - 1, 0))
     yh, yhs = hist_args(yhist, max(a.size - 1, 0))
-    if noalloc:   # the library's static scratch instead of a workspace; `out` must be given for the call to allocate nothing
+    if noalloc:   # the library's static scratch instead of a workspace
         check(lib().dspx_lfilter_f64_dev_noalloc(b.data_ptr(), b.numel(), a.ctypes.data, a.size, x2.data_ptr(), x2.stride(0),
                                                  xh, xhs, yh, yhs, o2.data_ptr(), o2.stride(0), nchan, n,
                                                  _flags(exact, mfma), _stream_ptr()))

@@ -8,6 +8,7 @@
 
 #include <cstring>
 #include <mutex>
+#include <string>
 
 #include "dspx.h"
 #include "dspx_common.h"
@@ -23,6 +24,7 @@ struct Rccl {
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     bool ok = false;
+    std::string why;  // why not, as the loader said it when it failed
 };
 
 const Rccl& rccl() {
@@ -33,8 +35,14 @@ const Rccl& rccl() {
         void* h = nullptr;
         for (const char* name : {"librccl.so", "librccl.so.1"})
             if (!h) h = dlopen(name, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
-        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
-            if (!h) h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            if (h) break;
+            h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (!h) {
+                const char* e = dlerror();  // (reading it clears it: once, right after the failure)
+                api.why = e ? e : "dlopen failed";
+            }
+        }
         if (!h) return;
         api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
         api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
@@ -42,12 +50,16 @@ const Rccl& rccl() {
         api.AllGather = reinterpret_cast<decltype(api.AllGather)>(dlsym(h, "ncclAllGather"));
         api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
         api.ok = api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.AllGather && api.GetErrorString;
+        if (!api.ok) {
+            const char* e = dlerror();
+            api.why = e ? e : "a symbol of the RCCL API is missing";
+        }
     });
     return api;
 }
 
 int need_rccl() {
-    return rccl().ok ? DSPX_OK : fail(DSPX_ERR_NO_DEVICE, "RCCL (librccl.so) could not be loaded: %s", dlerror() ? dlerror() : "symbols missing");
+    return rccl().ok ? DSPX_OK : fail(DSPX_ERR_NO_DEVICE, "RCCL (librccl.so) could not be loaded: %s", rccl().why.c_str());
 }
 
 #define DSPX_RCCL(call)                                                                              \
@@ -106,13 +118,24 @@ int dspx_allgather_f64_dev(dspx_comm* comm, const double* d_send, double* d_recv
     if (!comm) return fail(DSPX_ERR_INVALID, "comm is NULL");
     if (count && (!d_send || !d_recv)) return fail(DSPX_ERR_INVALID, "NULL buffer");
     if (count == 0) return DSPX_OK;
+    // the communicator, its buffers and the stream belong to the device it was created on
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess || cur != comm->device)
+        return fail(DSPX_ERR_INVALID, "the communicator was created on device %d, the current device is %d", comm->device, cur);
     DSPX_RCCL(rccl().AllGather(d_send, d_recv, count, ncclDouble, comm->comm, static_cast<hipStream_t>(stream)));
     return DSPX_OK;
 }
 
 void dspx_comm_destroy(dspx_comm* comm) {
     if (!comm) return;
-    if (comm->comm && rccl().ok) (void)rccl().CommDestroy(comm->comm);
+    if (comm->comm && rccl().ok) {
+        // destroyed with its own device current, whatever the caller's is (restored afterwards)
+        int cur = -1;
+        const bool have = hipGetDevice(&cur) == hipSuccess;
+        if (have && cur != comm->device) (void)hipSetDevice(comm->device);
+        (void)rccl().CommDestroy(comm->comm);
+        if (have && cur != comm->device) (void)hipSetDevice(cur);
+    }
     delete comm;
 }
 

@@ -154,7 +154,9 @@ DSPX_API int dspx_lfilter_f64_dev(const double* d_b, size_t nb, const double* a,
  * nchan, n) > DSPX_NOALLOC_SCRATCH_BYTES; launches of 1024 channels or more need only 20 KiB whatever n is) returns
  * DSPX_ERR_INVALID before anything is launched.  All calls on one GPU share that GPU's array: calls that overlap in
  * time on one GPU (different streams or threads) race; calls on one stream, or on different GPUs, do not.  Nothing in
- * the array has to start at zero (every call rewrites what it reads). */
+ * the array has to start at zero (every call rewrites what it reads).  The FIRST call on each GPU looks the array's
+ * device address up (hipGetSymbolAddress, which may load the code object): make one warm-up call per GPU outside any
+ * stream capture; every later call on that GPU only checks its arguments and launches kernels. */
 #define DSPX_NOALLOC_SCRATCH_BYTES ((size_t)16 << 20)
 DSPX_API int dspx_lfilter_f64_dev_noalloc(const double* d_b, size_t nb, const double* a, size_t na, const double* d_x,
                                           size_t x_stride, const double* d_xhist, size_t xhist_stride,

@@ -210,6 +210,48 @@ def test_bench_two_ranks_without_a_launcher():
     assert weak["allgather"].get("matches_per_rank_checksums") is True, weak["allgather"]
 
 
+def _visible_gpus() -> int:
+    import torch
+
+    return torch.cuda.device_count()   # (counting devices does not initialise the GPU)
+
+
+@pytest.mark.skipif(_visible_gpus() < 2, reason="needs two GPUs: RCCL refuses two ranks on one device")
+def test_rccl_allgather_two_ranks(tmp_path):
+    """dspx_comm_create / dspx_allgather_f64_dev with two ranks, one fresh process and one GPU each (started before
+    anything in them has touched a GPU; the id travels through a file): every rank receives both shards in rank
+    order, the result equals a torch.distributed all-gather over RCCL, and a call made with another device current is
+    refused."""
+    import json
+    import socket
+    import subprocess
+    import sys
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(here, "_rccl_pair_worker.py"), str(tmp_path / "id"),
+                                       str(tmp_path / f"result{r}.json")], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=240)[0])
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+    for r, p in enumerate(procs):
+        assert p.returncode == 0, outs[r][-3000:]
+        res = json.loads((tmp_path / f"result{r}.json").read_text())
+        assert res == {"rank": r, "ranks": 2, "gathered_equals_expected": True, "equals_torch_gather": True,
+                       "wrong_device_refused": True}
+
+
 def test_rccl_allgather_entry_point_single_rank(dsp):
     """dspx_comm_* / dspx_allgather_f64_dev: a communicator of one rank (all a one-GPU machine can hold; RCCL refuses
     two ranks on one device) gathers a shard onto itself.  The N-rank exchange runs in bench.py --gpus N."""

@@ -104,3 +104,55 @@ def test_sizes_beyond_the_scratch_are_refused(dsp):
                                                 None, 0, out.data_ptr(), n, nchan, n, 0, None)
     assert rc == -1 and b"static scratch" in dsp.lib().dspx_last_error()
     assert not out.any()
+
+
+def test_out_is_required(dsp):
+    import torch
+
+    x = torch.zeros(100, dtype=torch.float64, device="cuda")
+    with pytest.raises(ValueError, match="needs `out`"):
+        dsp.lfilter_iir_device(torch.ones(2, dtype=torch.float64, device="cuda"), np.array([1.0, -0.5]), x, noalloc=True)
+
+
+CAPTURE_CASES = [("tile-parallel tail, fused numerator", 3, 70001, 4, 0), ("walk form (1024 channels or more)", 1500, 20000, 2, 0),
+                 ("FIR pass first (40 taps), then the tail", 2, 50000, 2, 40), ("sequential exact tail", 4, 30000, 3, -1)]
+
+
+@pytest.mark.parametrize("what,nchan,n,order,ntaps", CAPTURE_CASES, ids=[c[0] for c in CAPTURE_CASES])
+def test_runs_under_stream_capture_and_allocates_nothing(dsp, oracle, what, nchan, n, order, ntaps):
+    """The contract itself: after one warm-up call on the device (which looks the scratch's address up) the entry point
+    is recorded inside a HIP stream capture -- where hipMalloc, hipFree and every synchronising call are errors that
+    invalidate the capture -- and the graph is replayed twice on fresh inputs.  Each replay must give the bits of
+    dspx_lfilter_f64_dev on the same input; and a plain call leaves the device's free memory where it was."""
+    import torch
+    from scipy import signal
+
+    exact = ntaps < 0
+    b, a = signal.butter(order, 0.2)
+    if ntaps > 0:
+        b = signal.firwin(ntaps, 0.3)
+    bt = torch.from_numpy(np.ascontiguousarray(b, dtype=np.float64)).cuda()
+    x = torch.empty((nchan, n), dtype=torch.float64, device="cuda")
+    y = torch.empty_like(x)
+    dsp.fill_splitmix(x, dsp.SEED, 1)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        dsp.lfilter_iir_device(bt, a, x, out=y, noalloc=True, exact=exact)   # warm-up: resolves the scratch on this device
+        side.synchronize()
+        free_before = torch.cuda.mem_get_info()[0]
+        dsp.lfilter_iir_device(bt, a, x, out=y, noalloc=True, exact=exact)
+        side.synchronize()
+        assert torch.cuda.mem_get_info()[0] == free_before, "the call changed the device's free memory"
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            dsp.lfilter_iir_device(bt, a, x, out=y, noalloc=True, exact=exact)
+    for seed_offset in (1 << 30, 1 << 31):
+        dsp.fill_splitmix(x, dsp.SEED, seed_offset)
+        y.fill_(float("nan"))
+        torch.cuda.synchronize()
+        graph.replay()
+        torch.cuda.synchronize()
+        want = dsp.lfilter_iir_device(bt, a, x, exact=exact)
+        assert np.array_equal(bits(y), bits(want)), what
+    xh = x[0].cpu().numpy()
+    assert scaled_err(y[0].cpu().numpy(), oracle.lfilter(b, a, xh)) <= 1e-12
