@@ -68,6 +68,8 @@ def parse_args():
     ap.add_argument("--no-weak", action="store_true", help="with strong scaling: skip the weak-scaling sub-record")
     ap.add_argument("--exact", action="store_true", help="DSPX_FIR_EXACT arithmetic (separate mul/add)")
     ap.add_argument("--vector", action="store_true", help="force the vector-pipe kernel (DSPX_FIR_VECTOR)")
+    ap.add_argument("--tiled", action="store_true",
+                    help="matrix pipe: the workgroup-tiled form of the kernel (DSPX_FIR_TILED), for A/B against the default")
     ap.add_argument("--allgather", action="store_true",
                     help="with --scaling strong and N > 1: also time an all-gather of the WHOLE result (reported apart); "
                          "without it a 64-channel slice per rank is gathered")
@@ -567,7 +569,7 @@ def main() -> None:
     torch.cuda.synchronize()
 
     def step():
-        dsp_amd.fir_device(taps, x, out=y, hist=hist, exact=args.exact, mfma=False if args.vector else None)
+        dsp_amd.fir_device(taps, x, out=y, hist=hist, exact=args.exact, mfma=False if args.vector else None, tiled=args.tiled)
 
     def fence():
         torch.cuda.synchronize()
@@ -646,10 +648,14 @@ def main() -> None:
 
     if rank == 0:
         matrix = not args.exact and not args.vector and numtaps >= dsp_amd.MATRIX_PIPE_MIN_TAPS
-        kernel_name = "fir_f64_mfma4_kernel (v_mfma_f64_4x4x4_4b_f64)" if matrix else "fir_f64_kernel (v_fma_f64)"
+        wave_form = matrix and not args.tiled and (numtaps + 2) // 4 + 1 <= 71   # one window serves the filter (<= 281 taps)
+        kernel_name = ("fir_f64_mfma4w_kernel (v_mfma_f64_4x4x4_4b_f64, wave-autonomous form)" if wave_form else
+                       "fir_f64_mfma4_kernel (v_mfma_f64_4x4x4_4b_f64, workgroup-tiled form)" if matrix else "fir_f64_kernel (v_fma_f64)")
         outputs_per_launch = nchan * n_local
         traffic, traffic_src = (load_traffic(args.workload) if (n_local == n and nchan == WORKLOADS[args.workload][0])
                                 else (None, "this rank's shard is not the profiled launch"))
+        if args.tiled or args.vector or args.exact:
+            traffic, traffic_src = None, "the profiled launch is the default kernel of this workload"
         flops = 2.0 * numtaps * outputs_per_launch
         bytes_alg = 16.0 * outputs_per_launch
         sec = kern_ms_max / 1e3
@@ -683,6 +689,7 @@ def main() -> None:
             "data": "synthetic (splitmix64 uniform [-1,1), generated on device, resident in HBM)",
             "config": {"workload": desc, "nchan_per_gpu": nchan, "samples_per_channel": n, "ntaps": numtaps,
                        "arithmetic": "exact (mul+add)" if args.exact else ("fma, matrix pipe" if matrix else "fma, vector pipe"),
+                       "kernel_form": "tiled (forced)" if (matrix and args.tiled) else "default",
                        "sharding": "none" if world == 1 else ("segments with history" if segments else "channels" if args.scaling == "strong"
                                                              else "independent batch per GPU")},
             "roofline": primary,

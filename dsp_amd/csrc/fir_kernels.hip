@@ -783,17 +783,25 @@ __global__ __launch_bounds__(kBlock, OB == 4 ? 2 : 4) void fir_f64_mfma4_kernel(
 // Wave-autonomous form of the matrix-pipe kernel for lfilter mode with a filter that one window serves (up to
 // 4 * kStageSteps - 3 = 281 taps) over 16-byte aligned buffers.  Same products, same order, same bits as
 // fir_f64_mfma4_kernel; what differs is who shares what:
-//   * every WAVE has an LDS image of its own (halo + 512 outputs' worth of samples) and walks a run of consecutive
-//     512-output chunks of one channel.  Nothing but the read-only tap table is shared between the waves of a
-//     workgroup, so there is no workgroup barrier after the table has been written: the LDS instructions of one wave
-//     execute in order, which is all the hand-over between a wave's own phases needs;
-//   * the halo of chunk k + 1 is the tail of chunk k's image: it is moved inside LDS (at most three 16-byte reads
-//     and writes per lane), so every sample of a run is fetched from memory exactly once, 64 bytes per lane and chunk;
-//   * results are transposed through the front of the wave's own image (dead once the products are done), read back
-//     in output order, 512 contiguous bytes per store instruction, and stored one chunk late like in the
-//     workgroup-tiled kernel.
-// Per chunk a wave issues, besides its matrix instructions, 4 loads, 8 stores, 26 LDS instructions and about two
-// dozen vector instructions, and waits for nobody but itself.
+//   * every WAVE has an LDS image of its own (halo + 512 outputs' worth of samples, 6.8 KB) and walks a run of
+//     consecutive 512-output chunks of one channel.  Nothing but the read-only tap table is shared between the waves
+//     of a workgroup, so there is no workgroup barrier after the table has been written: the LDS instructions of one
+//     wave execute in order, which is all the hand-over between a wave's own phases needs;
+//   * the halo of chunk k + 1 is the tail of chunk k's image: it is read into registers while the products of chunk k
+//     start and written to its new place when they are done (at most three 16-byte reads and writes per lane), so
+//     every sample of a run is fetched from memory exactly once, 64 bytes per lane and chunk (measured: HBM read
+//     traffic within 0.1 % of the algorithmic 8 bytes per output, where the workgroup-tiled form re-reads 11 %);
+//   * results are transposed through the body's place in the wave's own image (dead once the products are done),
+//     read back in output order, 512 contiguous bytes per store instruction, and stored one chunk late, after the
+//     next chunk's loads and first LDS reads have been issued.
+// Per chunk a wave issues, besides its matrix instructions, 4 loads, 8 stores, about 30 LDS instructions and about
+// two dozen vector instructions, and waits for nobody but itself: between the last matrix instruction of a chunk and
+// the first of the next lies one LDS round trip.
+//
+// What bounds it (timestamps inside the kernel, tools/m4w_timing.py; builds with the loads or the stores left out):
+// the product loop's marginal cost is exactly its matrix-pipe time, the pipe is occupied 87 % (101 taps) to 95 %
+// (255 taps) of the time, and the clock the chip holds falls with the HBM traffic the kernel drives -- 2.0 GHz at
+// 101 taps (4.1 TB/s), 2.2 GHz at 255 taps (2.1 TB/s), 2.26 / 2.35 GHz for the same kernels without their loads.
 #ifndef M4W_ABLATE
 // Development builds only (tools/build_variant.sh): 2 leaves out the result stores, 16 the sample loads of the steady
 // state, to time the kernel without that memory traffic.  The results of such a build are wrong.

@@ -54,3 +54,17 @@ def scaled_err(y, y_ref):
         return 0.0
     den = float(np.max(np.abs(y_ref)))
     return float(np.max(np.abs(y - y_ref))) / (den if den > 0 else 1.0)
+
+
+def cwt_row_tolerance(oracle, sig, scale, psi, wx, base=1e-12):
+    """Parity bound of one row of the wavelet bank, derived from what the row is: the first difference of the
+    convolution c of the signal with the scale's gathered wavelet, times -sqrt(scale) (reference dsp.hpp:1185-1191).
+    The kernels match the reference's c to `base` of max|c| (a different order of the same products); the
+    difference of two neighbouring values of c then carries that error against a result of size max|c[i+1] - c[i]|.
+    So a row is held to base * max|c| / max|diff c| (never less than base), measured on the row's own c."""
+    sig, psi, wx = (np.asarray(a, dtype=np.float64) for a in (sig, psi, wx))
+    step, rng = wx[1] - wx[0], wx[-1] - wx[0]
+    idx = oracle.cwt_scale_indices(float(scale), float(step), float(rng), psi.size, int(np.ceil(scale * rng)) + 1)
+    c = np.convolve(sig, psi[idx][::-1])
+    d = np.abs(np.diff(c)).max() if c.size > 1 else 0.0
+    return base * max(1.0, float(np.abs(c).max()) / d) if d > 0 else base

@@ -4,7 +4,7 @@ misaligned strides, optional history, every pipe flag; and the same for the recu
 import numpy as np
 import pytest
 
-from conftest import scaled_err
+from conftest import cwt_row_tolerance, scaled_err
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-12
@@ -143,4 +143,8 @@ def test_wavelet_bank_fuzz(env, oracle, golden):
         got = dsp.cwt(sig, scales, psi, wx, mfma=[None, True, False][case % 3])
         assert got.shape == ref.shape
         for r in range(ref.shape[0]):
-            assert scaled_err(got[r], ref[r]) <= 1e-11, (case, n, np.sort(scales)[r])
+            # (rows with NaN padding, where the reference has fewer values than samples, compare where both are finite)
+            ok = np.isfinite(ref[r])
+            assert np.array_equal(ok, np.isfinite(got[r])), (case, n, np.sort(scales)[r])
+            tol = cwt_row_tolerance(oracle, sig, np.sort(scales)[r], psi, wx)
+            assert scaled_err(got[r][ok], ref[r][ok]) <= tol, (case, n, np.sort(scales)[r], tol)
