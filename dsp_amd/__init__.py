@@ -10,5 +10,5 @@ Layout:
 The C++ drop-in header is include/dsp.hpp; the C ABI is include/dspx.h.
 """
 from ._lib import DspxError, lib  # noqa: F401
-from .api import (MATRIX_PIPE_MIN_TAPS, SEED, Comm, CwtBank, allgather_channels, channel_range, checksum, cwt, cwt_plan, integrate_wavelet, device_count, fill_splitmix, fir_device, fir_f32_device, fir_plan, firwin, lfilter, lfilter_f32,  # noqa: F401
+from .api import (MATRIX_PIPE_MIN_TAPS, SEED, Comm, CwtBank, allgather_channels, channel_range, checksum, cwt, cwt_plan, integrate_wavelet, device_count, fill_splitmix, fir_device, fir_f32_device, fir_plan, firwin, lfilter, lfilter_f32, lfilter_f64_from_f32,  # noqa: F401
                   lfilter_iir, lfilter_iir_device, lfilter_iir_stream, lfilter_multi, lfilter_stream, release_staging)

@@ -55,6 +55,13 @@ SIGNATURES = {
                                                C.c_size_t, C.c_size_t, C.c_uint, C.c_void_p]),
     "dspx_fir_f32": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t]),
     "dspx_fir_f32_from_f64": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "dspx_fir_f64_from_f32": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "dspx_fir_f64_from_f32_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                            C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p]),
+    "dspx_lfilter_f32": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p,
+                                   C.c_size_t]),
+    "dspx_lfilter_f32_from_f64": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p,
+                                            C.c_void_p, C.c_size_t]),
     "dspx_fir_f32_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p,
                                    C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p]),
     "dspx_fir_f32_from_f64_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,

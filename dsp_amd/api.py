@@ -73,19 +73,37 @@ def lfilter(b, x, exact: bool = False, mfma=None, out=None) -> np.ndarray:
     return y
 
 
-def lfilter_f32(b, x) -> np.ndarray:
-    """dsp::lfilter<float>(b, 1.0f, x) for 1-D host arrays.  float32 taps and samples: products in float
-    (dspx_fir_f32); anything else is taken as double: products in double, rounded to float, float sums
-    (dspx_fir_f32_from_f64, what the reference computes for containers of double)."""
+def lfilter_f32(b, x, a=None) -> np.ndarray:
+    """dsp::lfilter<float>(b, a, x) for 1-D host arrays (a = None: no recursive part).  float32 taps and samples:
+    products in float (dspx_fir_f32 / dspx_lfilter_f32); anything else is taken as double: products in double, rounded
+    to float, float sums (dspx_fir_f32_from_f64 / dspx_lfilter_f32_from_f64, what the reference computes for containers
+    of double).  The tail is evaluated in float for float32 denominators and in double otherwise, as the reference's
+    promotion rules have it."""
     b, x = np.asarray(b), np.asarray(x)
-    if b.dtype == np.float32 and x.dtype == np.float32:
+    narrow = b.dtype == np.float32 and x.dtype == np.float32
+    if narrow:
         b, x = np.ascontiguousarray(b), np.ascontiguousarray(x)
-        y = np.empty(x.size, dtype=np.float32)
-        check(lib().dspx_fir_f32(b.ctypes.data, b.size, x.ctypes.data, y.ctypes.data, x.size))
-        return y
-    b, x = _np_f64(b), _np_f64(x)
+    else:
+        b, x = _np_f64(b), _np_f64(x)
     y = np.empty(x.size, dtype=np.float32)
-    check(lib().dspx_fir_f32_from_f64(b.ctypes.data, b.size, x.ctypes.data, y.ctypes.data, x.size))
+    if a is None or np.size(a) <= 1:
+        fn = lib().dspx_fir_f32 if narrow else lib().dspx_fir_f32_from_f64
+        check(fn(b.ctypes.data, b.size, x.ctypes.data, y.ctypes.data, x.size))
+        return y
+    a = np.asarray(a)
+    in_double = 0 if a.dtype == np.float32 else 1
+    a64 = _np_f64(a)
+    fn = lib().dspx_lfilter_f32 if narrow else lib().dspx_lfilter_f32_from_f64
+    check(fn(b.ctypes.data, b.size, a64.ctypes.data, a64.size, in_double, x.ctypes.data, y.ctypes.data, x.size))
+    return y
+
+
+def lfilter_f64_from_f32(b, x) -> np.ndarray:
+    """dsp::lfilter<double>(b, 1.0, x) over float32 taps and samples: float products, double sums (dspx_fir_f64_from_f32)."""
+    b = np.ascontiguousarray(b, dtype=np.float32)
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    y = np.empty(x.size, dtype=np.float64)
+    check(lib().dspx_fir_f64_from_f32(b.ctypes.data, b.size, x.ctypes.data, y.ctypes.data, x.size))
     return y
 
 

@@ -618,10 +618,11 @@ int host_path_body(const double* taps, size_t ntaps, const double* hist0, const 
 }
 
 
-// lfilter<float>: TIN is the type the products are formed in (float or double containers), the result is float.
-template <typename TIN>
+// lfilter over narrow element types: TIN is the type the products are formed in (float or double containers), TOUT the
+// result type (float: the reference's lfilter<float>; double with TIN = float: lfilter<double> over containers of float).
+template <typename TIN, typename TOUT>
 int narrow_dev(const TIN* d_taps, size_t ntaps, const TIN* d_x, size_t x_stride, const TIN* d_hist, size_t hist_stride,
-               float* d_y, size_t y_stride, size_t nchan, size_t n, hipStream_t stream) {
+               TOUT* d_y, size_t y_stride, size_t nchan, size_t n, hipStream_t stream) {
     if (ntaps > 0x7fffffffull) return fail(DSPX_ERR_INVALID, "ntaps too large: %zu", ntaps);
     if (ntaps && !d_taps) return fail(DSPX_ERR_INVALID, "taps is NULL");
     if (nchan && n && (!d_x || !d_y)) return fail(DSPX_ERR_INVALID, "x or y is NULL");
@@ -630,7 +631,7 @@ int narrow_dev(const TIN* d_taps, size_t ntaps, const TIN* d_x, size_t x_stride,
         return fail(DSPX_ERR_INVALID, "channel stride smaller than n (%zu): x %zu, y %zu", n, x_stride, y_stride);
     if (d_hist && nchan > 1 && ntaps > 1 && hist_stride < ntaps - 1)
         return fail(DSPX_ERR_INVALID, "hist_stride (%zu) < ntaps-1", hist_stride);
-    if (ranges_overlap(d_x, ((nchan - 1) * x_stride + n) * sizeof(TIN), d_y, ((nchan - 1) * y_stride + n) * sizeof(float)))
+    if (ranges_overlap(d_x, ((nchan - 1) * x_stride + n) * sizeof(TIN), d_y, ((nchan - 1) * y_stride + n) * sizeof(TOUT)))
         return fail(DSPX_ERR_INVALID, "d_x and d_y overlap");
     const size_t tile = (size_t)dspx::fir_tile(), tiles_per_chan = (n + tile - 1) / tile;
     if (tiles_per_chan > kMaxGrid) return fail(DSPX_ERR_INVALID, "n too large for one launch: %zu", n);
@@ -644,7 +645,9 @@ int narrow_dev(const TIN* d_taps, size_t ntaps, const TIN* d_x, size_t x_stride,
         s.tiles_per_chan = (unsigned)tiles_per_chan;
         s.ntaps = (int)ntaps;
         const TIN* h = d_hist ? d_hist + c0 * hist_stride : nullptr;
-        if constexpr (std::is_same_v<TIN, float>)
+        if constexpr (std::is_same_v<TOUT, double>)
+            DSPX_HIP(dspx::launch_fir_f64_from_f32(d_taps, d_x + c0 * x_stride, h, d_y + c0 * y_stride, s, stream));
+        else if constexpr (std::is_same_v<TIN, float>)
             DSPX_HIP(dspx::launch_fir_f32(d_taps, d_x + c0 * x_stride, h, d_y + c0 * y_stride, s, stream));
         else
             DSPX_HIP(dspx::launch_fir_f32_from_f64(d_taps, d_x + c0 * x_stride, h, d_y + c0 * y_stride, s, stream));
@@ -652,23 +655,37 @@ int narrow_dev(const TIN* d_taps, size_t ntaps, const TIN* d_x, size_t x_stride,
     return DSPX_OK;
 }
 
-// Host pointers, one channel: plain allocate / copy / filter / copy back (no staging pipeline: this path is functional).
-template <typename TIN> int narrow_host(const TIN* taps, size_t ntaps, const TIN* x, float* y, size_t n) {
+// Host pointers, one channel: plain allocate / copy / filter / copy back (no staging pipeline: these paths are
+// functional).  With float results, `a` (na > 1) adds the recursive tail of lfilter<float> in place on the device.
+template <typename TIN, typename TOUT>
+int narrow_host(const TIN* taps, size_t ntaps, const double* a, size_t na, bool tail_in_double, const TIN* x, TOUT* y,
+                size_t n) {
     if (ntaps && !taps) return fail(DSPX_ERR_INVALID, "taps is NULL");
     if (n && (!x || !y)) return fail(DSPX_ERR_INVALID, "x or y is NULL");
+    dspx::IirCoef coef{};
+    const int order = na > 1 ? (int)(na - 1) : 0;
+    if (order) {
+        if (!a) return fail(DSPX_ERR_INVALID, "denominators is NULL");
+        if (order > dspx::kIirMaxOrder)
+            return fail(DSPX_ERR_INVALID, "at most %d denominator coefficients are supported, got %zu", dspx::kIirMaxOrder + 1, na);
+        for (int j = 0; j < order; ++j) coef.a[j] = a[j + 1];  // a[0] is never read (dsp.hpp:366 starts at j = 1)
+    }
     if (n == 0) return DSPX_OK;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(DSPX_ERR_NO_DEVICE, "no HIP device");
     TIN *d_taps = nullptr, *d_x = nullptr;
-    float* d_y = nullptr;
+    TOUT* d_y = nullptr;
     auto body = [&]() -> int {
         DSPX_HIP(hipMalloc((void**)&d_taps, std::max<size_t>(ntaps, 1) * sizeof(TIN)));
         DSPX_HIP(hipMalloc((void**)&d_x, n * sizeof(TIN)));
-        DSPX_HIP(hipMalloc((void**)&d_y, n * sizeof(float)));
+        DSPX_HIP(hipMalloc((void**)&d_y, n * sizeof(TOUT)));
         if (ntaps) DSPX_HIP(hipMemcpy(d_taps, taps, ntaps * sizeof(TIN), hipMemcpyHostToDevice));
         DSPX_HIP(hipMemcpy(d_x, x, n * sizeof(TIN), hipMemcpyHostToDevice));
-        if (int rc = narrow_dev<TIN>(d_taps, ntaps, d_x, n, nullptr, 0, d_y, n, 1, n, nullptr)) return rc;
-        DSPX_HIP(hipMemcpy(y, d_y, n * sizeof(float), hipMemcpyDeviceToHost));
+        if (int rc = narrow_dev<TIN, TOUT>(d_taps, ntaps, d_x, n, nullptr, 0, d_y, n, 1, n, nullptr)) return rc;
+        if constexpr (std::is_same_v<TOUT, float>) {
+            if (order) DSPX_HIP(dspx::launch_iir_narrow_tail(coef, order, tail_in_double, d_y, n, 1, (long long)n, nullptr));
+        }
+        DSPX_HIP(hipMemcpy(y, d_y, n * sizeof(TOUT), hipMemcpyDeviceToHost));
         return DSPX_OK;
     };
     const int rc = body();
@@ -941,24 +958,44 @@ int dspx_lfilter_f64_dev_noalloc(const double* d_b, size_t nb, const double* a, 
 }
 
 int dspx_fir_f32(const float* taps, size_t ntaps, const float* x, float* y, size_t n) {
-    return dspx::guarded([&] { return narrow_host<float>(taps, ntaps, x, y, n); });
+    return dspx::guarded([&] { return narrow_host<float, float>(taps, ntaps, nullptr, 0, false, x, y, n); });
 }
 
 int dspx_fir_f32_from_f64(const double* taps, size_t ntaps, const double* x, float* y, size_t n) {
-    return dspx::guarded([&] { return narrow_host<double>(taps, ntaps, x, y, n); });
+    return dspx::guarded([&] { return narrow_host<double, float>(taps, ntaps, nullptr, 0, false, x, y, n); });
+}
+
+int dspx_fir_f64_from_f32(const float* taps, size_t ntaps, const float* x, double* y, size_t n) {
+    return dspx::guarded([&] { return narrow_host<float, double>(taps, ntaps, nullptr, 0, false, x, y, n); });
+}
+
+int dspx_lfilter_f32(const float* b, size_t nb, const double* a, size_t na, int tail_in_double, const float* x, float* y,
+                     size_t n) {
+    return dspx::guarded([&] { return narrow_host<float, float>(b, nb, a, na, tail_in_double != 0, x, y, n); });
+}
+
+int dspx_lfilter_f32_from_f64(const double* b, size_t nb, const double* a, size_t na, int tail_in_double, const double* x,
+                              float* y, size_t n) {
+    return dspx::guarded([&] { return narrow_host<double, float>(b, nb, a, na, tail_in_double != 0, x, y, n); });
+}
+
+int dspx_fir_f64_from_f32_dev(const float* d_taps, size_t ntaps, const float* d_x, size_t x_stride, const float* d_hist,
+                              size_t hist_stride, double* d_y, size_t y_stride, size_t nchan, size_t n, void* stream) {
+    return narrow_dev<float, double>(d_taps, ntaps, d_x, x_stride, d_hist, hist_stride, d_y, y_stride, nchan, n,
+                                     static_cast<hipStream_t>(stream));
 }
 
 int dspx_fir_f32_dev(const float* d_taps, size_t ntaps, const float* d_x, size_t x_stride, const float* d_hist,
                      size_t hist_stride, float* d_y, size_t y_stride, size_t nchan, size_t n, void* stream) {
-    return narrow_dev<float>(d_taps, ntaps, d_x, x_stride, d_hist, hist_stride, d_y, y_stride, nchan, n,
-                             static_cast<hipStream_t>(stream));
+    return narrow_dev<float, float>(d_taps, ntaps, d_x, x_stride, d_hist, hist_stride, d_y, y_stride, nchan, n,
+                                    static_cast<hipStream_t>(stream));
 }
 
 int dspx_fir_f32_from_f64_dev(const double* d_taps, size_t ntaps, const double* d_x, size_t x_stride,
                               const double* d_hist, size_t hist_stride, float* d_y, size_t y_stride, size_t nchan,
                               size_t n, void* stream) {
-    return narrow_dev<double>(d_taps, ntaps, d_x, x_stride, d_hist, hist_stride, d_y, y_stride, nchan, n,
-                              static_cast<hipStream_t>(stream));
+    return narrow_dev<double, float>(d_taps, ntaps, d_x, x_stride, d_hist, hist_stride, d_y, y_stride, nchan, n,
+                                     static_cast<hipStream_t>(stream));
 }
 
 long dspx_fir_plan(size_t nchan, size_t n, int ngpus, dspx_piece* out, size_t cap) {

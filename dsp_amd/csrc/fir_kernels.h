@@ -62,6 +62,9 @@ hipError_t launch_fir_f32(const float* taps, const float* x, const float* hist, 
                           hipStream_t stream);
 hipError_t launch_fir_f32_from_f64(const double* taps, const double* x, const double* hist, float* y,
                                    const FirShape& shape, hipStream_t stream);
+// lfilter<double> over containers of float: float products, widened and added to a double sum.
+hipError_t launch_fir_f64_from_f32(const float* taps, const float* x, const float* hist, double* y,
+                                   const FirShape& shape, hipStream_t stream);
 hipError_t launch_fill_splitmix(double* x, unsigned long long n, unsigned long long seed, unsigned long long offset,
                                 hipStream_t stream);
 hipError_t launch_checksum(const double* y, unsigned long long n, unsigned long long offset, unsigned long long* out,

@@ -1119,18 +1119,19 @@ __global__ __launch_bounds__(kBlock, RESIDENT) void fir_f64_mfma4w_kernel(const 
 }
 
 // ---------------------------------------------------------------------------------------------
-// lfilter<float> (reference dsp.hpp:361-364 with T = float): the sum is a float, and every product is formed in the
-// type the operands promote to -- double for containers of double, float for containers of float -- converted to
-// float and added, taps ascending.  TIN is that operand type.  Separately rounded operations in exactly the
+// lfilter over narrow element types (reference dsp.hpp:361-364): the sum has the result type TOUT, and every product
+// is formed in TIN, the type the containers' elements promote to -- float for containers of float, double for
+// containers of double -- converted to TOUT and added, taps ascending.  Separately rounded operations in exactly the
 // reference's order, so the results are bit-identical to the reference loop; a product with a sample that does not
-// exist (before the start of a channel without history) is never formed.  A functional path for the reference's
-// single-precision instantiation, not a tuned one: one workgroup per tile of 2048 outputs, thread t owns outputs
+// exist (before the start of a channel without history) is never formed.  <float, float> and <double, float> are the
+// reference's lfilter<float>, <float, double> is lfilter<double> over containers of float (float products, double
+// sum).  Functional paths, not tuned ones: one workgroup per tile of 2048 outputs, thread t owns outputs
 // t, t + 256, ..., taps and samples through LDS in chunks of 256 taps.
 constexpr int kNarrowTaps = 256;
-template <typename TIN>
-__global__ __launch_bounds__(kBlock) void fir_f32_kernel(const TIN* __restrict__ taps, const TIN* __restrict__ x,
-                                                          const TIN* __restrict__ hist, float* __restrict__ y,
-                                                          FirShape s) {
+template <typename TIN, typename TOUT>
+__global__ __launch_bounds__(kBlock) void fir_narrow_kernel(const TIN* __restrict__ taps, const TIN* __restrict__ x,
+                                                             const TIN* __restrict__ hist, TOUT* __restrict__ y,
+                                                             FirShape s) {
     __shared__ TIN xs[kNarrowTaps - 1 + kTile];
     __shared__ TIN tapl[kNarrowTaps];
     const int tid = threadIdx.x;
@@ -1139,11 +1140,11 @@ __global__ __launch_bounds__(kBlock) void fir_f32_kernel(const TIN* __restrict__
     const int ntaps = s.ntaps;
     const TIN* __restrict__ xc = x + (unsigned long long)chan * s.x_stride;
     const TIN* __restrict__ hc = hist ? hist + (unsigned long long)chan * s.hist_stride : nullptr;
-    float acc[kR];
+    TOUT acc[kR];
     long long jmax[kR];  // output r adds taps j < jmax[r]: all of them, or as many as there are samples behind it
 #pragma unroll
     for (int r = 0; r < kR; ++r) {
-        acc[r] = 0.0f;
+        acc[r] = 0;
         const long long i = tile_start + tid + r * kBlock;
         jmax[r] = hc ? (long long)ntaps : min((long long)ntaps, i + 1);
     }
@@ -1168,7 +1169,8 @@ __global__ __launch_bounds__(kBlock) void fir_f32_kernel(const TIN* __restrict__
 #pragma unroll
             for (int r = 0; r < kR; ++r) {
 #pragma clang fp contract(off)
-                const float term = static_cast<float>(b * xs[kNarrowTaps - 1 + tid + r * kBlock - jj]);
+                const TIN prod = b * xs[kNarrowTaps - 1 + tid + r * kBlock - jj];
+                const TOUT term = static_cast<TOUT>(prod);
                 if (j0 + jj < jmax[r]) acc[r] = acc[r] + term;
             }
         }
@@ -1345,21 +1347,25 @@ hipError_t launch_fir_bank_f64(const double* taps, const BankRow* bank, const do
     return hipGetLastError();
 }
 
-template <typename TIN>
-static hipError_t launch_fir_f32_any(const TIN* taps, const TIN* x, const TIN* hist, float* y, const FirShape& shape,
-                                     hipStream_t stream) {
+template <typename TIN, typename TOUT>
+static hipError_t launch_fir_narrow(const TIN* taps, const TIN* x, const TIN* hist, TOUT* y, const FirShape& shape,
+                                    hipStream_t stream) {
     if (shape.total_tiles == 0) return hipSuccess;
     if (!grid_fits(shape.total_tiles)) return hipErrorInvalidConfiguration;
-    hipLaunchKernelGGL(fir_f32_kernel<TIN>, dim3(shape.total_tiles), dim3(kBlock), 0, stream, taps, x, hist, y, shape);
+    hipLaunchKernelGGL((fir_narrow_kernel<TIN, TOUT>), dim3(shape.total_tiles), dim3(kBlock), 0, stream, taps, x, hist, y, shape);
     return hipGetLastError();
 }
 hipError_t launch_fir_f32(const float* taps, const float* x, const float* hist, float* y, const FirShape& shape,
                           hipStream_t stream) {
-    return launch_fir_f32_any<float>(taps, x, hist, y, shape, stream);
+    return launch_fir_narrow<float, float>(taps, x, hist, y, shape, stream);
 }
 hipError_t launch_fir_f32_from_f64(const double* taps, const double* x, const double* hist, float* y,
                                    const FirShape& shape, hipStream_t stream) {
-    return launch_fir_f32_any<double>(taps, x, hist, y, shape, stream);
+    return launch_fir_narrow<double, float>(taps, x, hist, y, shape, stream);
+}
+hipError_t launch_fir_f64_from_f32(const float* taps, const float* x, const float* hist, double* y,
+                                   const FirShape& shape, hipStream_t stream) {
+    return launch_fir_narrow<float, double>(taps, x, hist, y, shape, stream);
 }
 
 hipError_t launch_fill_splitmix(double* x, unsigned long long n, unsigned long long seed, unsigned long long offset,

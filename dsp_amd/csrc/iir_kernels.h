@@ -84,5 +84,9 @@ hipError_t launch_iir_scan(const IirCoef& coef, int order, double* y, const doub
 // bit-identical to dsp.hpp:366-368; otherwise one fused multiply-add per coefficient.
 hipError_t launch_iir_sequential(const IirCoef& coef, int order, double* y, const double* state_in,
                                  const IirShape& shape, bool exact, hipStream_t stream);
+// The tail of lfilter<float> (dsp.hpp:366-368 with T = float) in place on float outputs; `in_double`: products and
+// differences in double (double denominators) instead of float.
+hipError_t launch_iir_narrow_tail(const IirCoef& coef, int order, bool in_double, float* y, unsigned long long y_stride,
+                                  unsigned long long nchan, long long n, hipStream_t stream);
 
 }  // namespace dspx

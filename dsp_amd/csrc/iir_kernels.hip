@@ -440,6 +440,42 @@ __global__ __launch_bounds__(kBlock) void iir_walk_kernel(IirCoef coef, IirFront
     }
 }
 
+// The recursive tail of lfilter<float> (reference dsp.hpp:366-368 with T = float), in place on the FIR part: one lane
+// per channel, samples in order.  `y_i -= denominators[j] * y[i-j]` is evaluated in PT, the type denominators[j] * float
+// promotes to (float for float denominators, double for double ones): the product and the difference are rounded
+// separately in PT and the difference is converted back to float, j ascending -- bit-identical to the reference loop.
+// Functional, not fast: the recurrence is sequential along a channel.
+template <typename PT>
+__global__ __launch_bounds__(64) void iir_narrow_tail_kernel(IirCoef coef, int order, float* __restrict__ y,
+                                                             unsigned long long y_stride, unsigned long long nchan,
+                                                             long long n) {
+    const unsigned long long c = (unsigned long long)blockIdx.x * 64 + threadIdx.x;
+    if (c >= nchan) return;
+    float* __restrict__ yc = y + c * y_stride;
+    PT a[kIirMaxOrder];
+#pragma unroll
+    for (int j = 0; j < kIirMaxOrder; ++j) a[j] = static_cast<PT>(coef.a[j]);
+    float st[kIirMaxOrder];  // st[j] = y[i - 1 - j]
+#pragma unroll
+    for (int j = 0; j < kIirMaxOrder; ++j) st[j] = 0.0f;
+    for (long long i = 0; i < n; ++i) {
+        float v = yc[i];
+#pragma unroll
+        for (int j = 0; j < kIirMaxOrder; ++j) {
+            if (j < order && j < i) {
+#pragma clang fp contract(off)
+                const PT prod = a[j] * static_cast<PT>(st[j]);
+                const PT diff = static_cast<PT>(v) - prod;
+                v = static_cast<float>(diff);
+            }
+        }
+#pragma unroll
+        for (int k = kIirMaxOrder - 1; k > 0; --k) st[k] = st[k - 1];
+        st[0] = v;
+        yc[i] = v;
+    }
+}
+
 // 64 channels per workgroup (one wave), one lane per channel, 64 samples per pass through LDS.
 constexpr int kSeqChans = 64, kSeqSamples = 64;
 template <int P, bool EXACT>
@@ -623,6 +659,17 @@ hipError_t launch_iir_sequential(const IirCoef& coef, int order, double* y, cons
 #define DSPX_IIR_SEQ(P) seq_path<P>(coef, y, state_in, shape, exact, stream)
     DSPX_IIR_DISPATCH(DSPX_IIR_SEQ)
 #undef DSPX_IIR_SEQ
+}
+
+hipError_t launch_iir_narrow_tail(const IirCoef& coef, int order, bool in_double, float* y, unsigned long long y_stride,
+                                  unsigned long long nchan, long long n, hipStream_t stream) {
+    if (nchan == 0 || n == 0 || order == 0) return hipSuccess;
+    const dim3 grid((unsigned)((nchan + 63) / 64)), block(64);
+    if (in_double)
+        hipLaunchKernelGGL(iir_narrow_tail_kernel<double>, grid, block, 0, stream, coef, order, y, y_stride, nchan, n);
+    else
+        hipLaunchKernelGGL(iir_narrow_tail_kernel<float>, grid, block, 0, stream, coef, order, y, y_stride, nchan, n);
+    return hipGetLastError();
 }
 
 }  // namespace dspx

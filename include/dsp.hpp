@@ -236,32 +236,68 @@ void lfilter(lfilter_ctx_t<T>& ctx, const Container_1& numerators, const Contain
     if (n == 0) return;
     int rc;
     if constexpr (std::is_same_v<T, float>) {
-        // single precision (dsp.hpp:361-364 with T = float): float sums of products formed in float or in double
+        // single precision (dsp.hpp:361-368 with T = float): float sums of products formed in float or in double; the
+        // tail y_i -= denominators[j] * y[i-j] in the type denominators[j] * float promotes to
         static_assert(std::is_same_v<product_t, float> || std::is_same_v<product_t, double>,
                       "dsp::lfilter<float> (MI355X): the products numerators * x must be formed in float or double");
-        if (denominators.size() > 1)
-            throw std::invalid_argument("dsp::lfilter<float> (MI355X): a recursive part is implemented for T = double only");
+        using tail_t = decltype(std::declval<V2>() * std::declval<float>());
+        static_assert(std::is_same_v<tail_t, float> || std::is_same_v<tail_t, double>,
+                      "dsp::lfilter<float> (MI355X): the products denominators * y must be formed in float or double");
         const detail::scalar_view<product_t, Container_1> b(numerators);
         const detail::scalar_view<product_t, Container_3> in(x);
-        if constexpr (std::is_same_v<product_t, float>)
-            rc = dspx_fir_f32(b.data(), b.size(), in.data(), ctx.result.data(), n);
-        else
-            rc = dspx_fir_f32_from_f64(b.data(), b.size(), in.data(), ctx.result.data(), n);
-    } else {
-        static_assert(std::is_same_v<product_t, double> &&
-                        std::is_same_v<decltype(std::declval<V2>() * std::declval<double>()), double>,
-                      "dsp::lfilter<double> (MI355X): the products numerators * x and denominators * y must be formed "
-                      "in double (e.g. double taps over float or integer samples)");
-        const detail::double_view<Container_1> b(numerators);
-        const detail::double_view<Container_3> in(x);
-        if (denominators.size() > 1) {  // the recursive tail, dsp.hpp:366-368
-            const detail::double_view<Container_2> a(denominators);
-            rc = dspx_lfilter_f64(b.data(), b.size(), a.data(), a.size(), in.data(), ctx.result.data(), 1, n, n,
-                                  DSPX_FIR_FMA);
+        if (denominators.size() > 1) {
+            // (converted to tail_t first, as the promotion would, then handed over as doubles, which is exact)
+            std::vector<double> a(denominators.size());
+            for (std::size_t j = 0; j < a.size(); ++j) a[j] = static_cast<double>(static_cast<tail_t>(denominators[j]));
+            constexpr int in_double = std::is_same_v<tail_t, double> ? 1 : 0;
+            if constexpr (std::is_same_v<product_t, float>)
+                rc = dspx_lfilter_f32(b.data(), b.size(), a.data(), a.size(), in_double, in.data(), ctx.result.data(), n);
+            else
+                rc = dspx_lfilter_f32_from_f64(b.data(), b.size(), a.data(), a.size(), in_double, in.data(), ctx.result.data(), n);
             if (rc == DSPX_ERR_INVALID)
                 throw std::invalid_argument(std::string("dsp::lfilter (MI355X): ") + dspx_last_error());
+        } else if constexpr (std::is_same_v<product_t, float>) {
+            rc = dspx_fir_f32(b.data(), b.size(), in.data(), ctx.result.data(), n);
         } else {
-            rc = dspx_fir_f64(b.data(), b.size(), in.data(), ctx.result.data(), n, DSPX_FIR_FMA);
+            rc = dspx_fir_f32_from_f64(b.data(), b.size(), in.data(), ctx.result.data(), n);
+        }
+    } else {
+        static_assert((std::is_same_v<product_t, double> || std::is_same_v<product_t, float>) &&
+                        std::is_same_v<decltype(std::declval<V2>() * std::declval<double>()), double>,
+                      "dsp::lfilter<double> (MI355X): the products numerators * x must be formed in double or float, "
+                      "those of denominators * y in double");
+        if constexpr (std::is_same_v<product_t, float>) {
+            // containers whose elements multiply in float (e.g. vector<float> taps over vector<float> samples): the
+            // reference forms float products and adds them to a double sum (dsp.hpp:363)
+            const detail::scalar_view<float, Container_1> b(numerators);
+            const detail::scalar_view<float, Container_3> in(x);
+            if (denominators.size() > 1) {
+                // FIR part first, then the tail (double arithmetic throughout) in place of a second FIR pass: a
+                // one-tap numerator of 1.0 reproduces its input exactly
+                std::vector<double> part(n);
+                rc = dspx_fir_f64_from_f32(b.data(), b.size(), in.data(), part.data(), n);
+                if (rc == DSPX_OK) {
+                    const detail::double_view<Container_2> a(denominators);
+                    const double one = 1.0;
+                    rc = dspx_lfilter_f64(&one, 1, a.data(), a.size(), part.data(), ctx.result.data(), 1, n, n, DSPX_FIR_EXACT);
+                    if (rc == DSPX_ERR_INVALID)
+                        throw std::invalid_argument(std::string("dsp::lfilter (MI355X): ") + dspx_last_error());
+                }
+            } else {
+                rc = dspx_fir_f64_from_f32(b.data(), b.size(), in.data(), ctx.result.data(), n);
+            }
+        } else {
+            const detail::double_view<Container_1> b(numerators);
+            const detail::double_view<Container_3> in(x);
+            if (denominators.size() > 1) {  // the recursive tail, dsp.hpp:366-368
+                const detail::double_view<Container_2> a(denominators);
+                rc = dspx_lfilter_f64(b.data(), b.size(), a.data(), a.size(), in.data(), ctx.result.data(), 1, n, n,
+                                      DSPX_FIR_FMA);
+                if (rc == DSPX_ERR_INVALID)
+                    throw std::invalid_argument(std::string("dsp::lfilter (MI355X): ") + dspx_last_error());
+            } else {
+                rc = dspx_fir_f64(b.data(), b.size(), in.data(), ctx.result.data(), n, DSPX_FIR_FMA);
+            }
         }
     }
     if (rc != DSPX_OK)

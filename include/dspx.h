@@ -196,6 +196,23 @@ DSPX_API int dspx_fir_f64_dev(const double* d_taps, size_t ntaps, const double* 
  * samples per channel as dspx_fir_f64_dev, and a stream. */
 DSPX_API int dspx_fir_f32(const float* taps, size_t ntaps, const float* x, float* y, size_t n);
 DSPX_API int dspx_fir_f32_from_f64(const double* taps, size_t ntaps, const double* x, float* y, size_t n);
+/* lfilter<double> over containers of float (dsp.hpp:361-364 with T = double): every product numerators[j] * x[i-j] is
+ * formed in float, converted to double and added to a double sum, taps ascending -- bit-identical to the reference. */
+DSPX_API int dspx_fir_f64_from_f32(const float* taps, size_t ntaps, const float* x, double* y, size_t n);
+DSPX_API int dspx_fir_f64_from_f32_dev(const float* d_taps, size_t ntaps, const float* d_x, size_t x_stride,
+                                       const float* d_hist, size_t hist_stride, double* d_y, size_t y_stride,
+                                       size_t nchan, size_t n, void* stream);
+/* lfilter<float> with a recursive part (dsp.hpp:356-369 with T = float): the FIR part as dspx_fir_f32 /
+ * dspx_fir_f32_from_f64, then y_i -= a[j] * y[i-j], j = 1 .. min(na, i+1) - 1, in place (a[0] is never read; na may be
+ * at most 9).  The reference evaluates that tail in the type denominators[j] * float promotes to: pass the
+ * denominators as doubles (float ones convert exactly) and tail_in_double = 0 for float denominators (float products
+ * and differences), 1 for double ones (double products and differences, converted to float).  Separately rounded
+ * operations in the reference's order: bit-identical to it.  One lane per channel, samples in order: functional, not
+ * fast (the tuned recursive path is dspx_lfilter_f64). */
+DSPX_API int dspx_lfilter_f32(const float* b, size_t nb, const double* a, size_t na, int tail_in_double, const float* x,
+                              float* y, size_t n);
+DSPX_API int dspx_lfilter_f32_from_f64(const double* b, size_t nb, const double* a, size_t na, int tail_in_double,
+                                       const double* x, float* y, size_t n);
 DSPX_API int dspx_fir_f32_dev(const float* d_taps, size_t ntaps, const float* d_x, size_t x_stride, const float* d_hist,
                               size_t hist_stride, float* d_y, size_t y_stride, size_t nchan, size_t n, void* stream);
 DSPX_API int dspx_fir_f32_from_f64_dev(const double* d_taps, size_t ntaps, const double* d_x, size_t x_stride,

@@ -173,6 +173,56 @@ void oracle_lfilter_f32_from_f64(const double* b, size_t nb, const double* x, si
     }
 }
 
+/* lfilter<double> over containers of float (dsp.hpp:361-364 with T = double): numerators[j] * x[i-j] is a float
+ * product, converted to double and added to a double sum. */
+void oracle_lfilter_f64_from_f32(const float* b, size_t nb, const float* x, size_t n, double* y) {
+    for (size_t i = 0; i < n; ++i) {
+        const size_t ip1 = i + 1;
+        const size_t nb_end = nb < ip1 ? nb : ip1;
+        double sum = 0.0;
+        for (size_t j = 0; j < nb_end; ++j) {
+            const float prod = b[j] * x[i - j];
+            sum += (double)prod;
+        }
+        y[i] = sum;
+    }
+}
+
+/* lfilter<float> with a recursive part (dsp.hpp:356-369 with T = float).  The tail `y_i -= denominators[j] * y[i-j]`
+ * is evaluated in the type denominators[j] * float promotes to: float for float denominators ... */
+void oracle_lfilter_f32_iir(const float* b, size_t nb, const float* a, size_t na, const float* x, size_t n, float* y) {
+    for (size_t i = 0; i < n; ++i) {
+        const size_t ip1 = i + 1;
+        const size_t nb_end = nb < ip1 ? nb : ip1, na_end = na < ip1 ? na : ip1;
+        float sum = 0.0f;
+        for (size_t j = 0; j < nb_end; ++j) sum += b[j] * x[i - j];
+        float yi = sum;
+        for (size_t j = 1; j < na_end; ++j) {
+            const float prod = a[j] * y[i - j];
+            yi = yi - prod;
+        }
+        y[i] = yi;
+    }
+}
+
+/* ... and double for double denominators (here over double numerators and samples as well, whose products are
+ * formed in double and converted to float before they are added, as in oracle_lfilter_f32_from_f64). */
+void oracle_lfilter_f32_from_f64_iir(const double* b, size_t nb, const double* a, size_t na, const double* x, size_t n,
+                                     float* y) {
+    for (size_t i = 0; i < n; ++i) {
+        const size_t ip1 = i + 1;
+        const size_t nb_end = nb < ip1 ? nb : ip1, na_end = na < ip1 ? na : ip1;
+        float sum = 0.0f;
+        for (size_t j = 0; j < nb_end; ++j) sum += (float)(b[j] * x[i - j]);
+        float yi = sum;
+        for (size_t j = 1; j < na_end; ++j) {
+            const double prod = a[j] * (double)y[i - j];
+            yi = (float)((double)yi - prod);
+        }
+        y[i] = yi;
+    }
+}
+
 /* Deterministic synthetic input shared by CPU and GPU:
  * x[idx] = ((mix(seed + (idx+1)*GAMMA) >> 11) * 2^-52) - 1.0, uniform in [-1, 1),
  * where mix() is the SplitMix64 finaliser.  Every value is exactly representable. */

@@ -106,6 +106,11 @@ def outputs() -> dict:
     z["iir2_b"] = np.array([1.0, 0.5, 0.25])
     z["iir2_a"] = np.array([1.0, 0.0, 0.81])
     z["iir2_y"] = ref.lfilter(z["iir2_b"], z["iir2_a"], xs)
+    # narrow element types: lfilter<double> over float containers, and lfilter<float> with a recursive part
+    xs32 = orc.fill_splitmix(3000, SEED, 4242).astype(np.float32)
+    z["f64_from_f32_y"] = ref.lfilter_f64_from_f32(z["taps_101_0p25"].astype(np.float32), xs32)
+    z["f32_iir_y"] = ref.lfilter_f32_iir(z["iir4_b"].astype(np.float32), z["iir4_a"].astype(np.float32), xs32)
+    z["f32_from_f64_iir_y"] = ref.lfilter_f32_from_f64_iir(z["iir4_b"], z["iir4_a"], orc.fill_splitmix(3000, SEED, 4242))
     # wavelet bank
     psi, wx = ref.integrate_wavelet(10)
     z["morlet10_psi"], z["morlet10_x"] = psi, wx

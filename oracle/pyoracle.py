@@ -56,6 +56,9 @@ class Oracle:
         L.oracle_lfilter_f32_from_f64.restype = None
         L.oracle_lfilter_f32_from_f64.argtypes = [_f64p, C.c_size_t, _f64p, C.c_size_t, _f32p]
         L.oracle_fill_splitmix_f64.restype = None
+        L.oracle_lfilter_f64_from_f32.argtypes = [_f32p, C.c_size_t, _f32p, C.c_size_t, _f64p]
+        L.oracle_lfilter_f32_iir.argtypes = [_f32p, C.c_size_t, _f32p, C.c_size_t, _f32p, C.c_size_t, _f32p]
+        L.oracle_lfilter_f32_from_f64_iir.argtypes = [_f64p, C.c_size_t, _f64p, C.c_size_t, _f64p, C.c_size_t, _f32p]
         L.oracle_fill_splitmix_f64.argtypes = [_f64p, C.c_size_t, C.c_uint64, C.c_uint64]
         L.oracle_checksum_f64.restype = C.c_uint64
         L.oracle_checksum_f64.argtypes = [_f64p, C.c_size_t, C.c_uint64]
@@ -123,6 +126,33 @@ class Oracle:
                                            y if y.size else np.zeros(1, np.float32))
         return y
 
+    def lfilter_f64_from_f32(self, b, x) -> np.ndarray:
+        """lfilter<double> over float containers: float products, widened, double sums."""
+        b = np.ascontiguousarray(b, dtype=np.float32)
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        y = np.empty(x.size, dtype=np.float64)
+        self.L.oracle_lfilter_f64_from_f32(b if b.size else np.zeros(1, np.float32), b.size,
+                                           x if x.size else np.zeros(1, np.float32), x.size, y if y.size else np.zeros(1))
+        return y
+
+    def lfilter_f32_iir(self, b, a, x) -> np.ndarray:
+        """lfilter<float> with a recursive part over float containers (tail in float)."""
+        b, a, x = (np.ascontiguousarray(v, dtype=np.float32) for v in (b, a, x))
+        y = np.empty(x.size, dtype=np.float32)
+        one = np.zeros(1, np.float32)
+        self.L.oracle_lfilter_f32_iir(b if b.size else one, b.size, a if a.size else one, a.size, x if x.size else one, x.size,
+                                      y if y.size else one)
+        return y
+
+    def lfilter_f32_from_f64_iir(self, b, a, x) -> np.ndarray:
+        """lfilter<float> with a recursive part over double containers (products and tail in double, float results)."""
+        b, a, x = _f64(b), _f64(a), _f64(x)
+        y = np.empty(x.size, dtype=np.float32)
+        one = np.zeros(1)
+        self.L.oracle_lfilter_f32_from_f64_iir(b if b.size else one, b.size, a if a.size else one, a.size,
+                                               x if x.size else one, x.size, y if y.size else np.zeros(1, np.float32))
+        return y
+
     def fill_splitmix(self, n: int, seed: int = SEED, offset: int = 0) -> np.ndarray:
         x = np.empty(n, dtype=np.float64)
         if n:
@@ -173,6 +203,9 @@ class Reference:
         L.ref_lfilter_scalar_den.argtypes = [_f64p, C.c_size_t, C.c_double, _f64p, C.c_size_t, _f64p]
         L.ref_lfilter_f32.argtypes = [_f32p, C.c_size_t, _f32p, C.c_size_t, _f32p]
         L.ref_lfilter_f32_from_f64.argtypes = [_f64p, C.c_size_t, _f64p, C.c_size_t, _f32p]
+        L.ref_lfilter_f64_from_f32.argtypes = [_f32p, C.c_size_t, _f32p, C.c_size_t, _f64p]
+        L.ref_lfilter_f32_iir.argtypes = [_f32p, C.c_size_t, _f32p, C.c_size_t, _f32p, C.c_size_t, _f32p]
+        L.ref_lfilter_f32_from_f64_iir.argtypes = [_f64p, C.c_size_t, _f64p, C.c_size_t, _f64p, C.c_size_t, _f32p]
         L.ref_integrate_wavelet.argtypes = [C.c_size_t, _f64p, _f64p]
         L.ref_cwt.argtypes = [_f64p, C.c_size_t, _f64p, C.c_size_t, _f64p, _f64p, C.c_size_t, _f64p]
         self.L = L
@@ -231,6 +264,25 @@ class Reference:
         y = np.empty(max(x.size, 1), dtype=np.float32)
         rc = self.L.ref_lfilter_f32_from_f64(b if b.size else np.zeros(1), b.size, x if x.size else np.zeros(1), x.size, y)
         assert rc == 0
+        return y[: x.size]
+
+    def lfilter_f64_from_f32(self, b, x):
+        b = np.ascontiguousarray(b, dtype=np.float32)
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        y = np.empty(max(x.size, 1), dtype=np.float64)
+        assert self.L.ref_lfilter_f64_from_f32(b, b.size, x, x.size, y) == 0
+        return y[: x.size]
+
+    def lfilter_f32_iir(self, b, a, x):
+        b, a, x = (np.ascontiguousarray(v, dtype=np.float32) for v in (b, a, x))
+        y = np.empty(max(x.size, 1), dtype=np.float32)
+        assert self.L.ref_lfilter_f32_iir(b, b.size, a, a.size, x, x.size, y) == 0
+        return y[: x.size]
+
+    def lfilter_f32_from_f64_iir(self, b, a, x):
+        b, a, x = _f64(b), _f64(a), _f64(x)
+        y = np.empty(max(x.size, 1), dtype=np.float32)
+        assert self.L.ref_lfilter_f32_from_f64_iir(b, b.size, a, a.size, x, x.size, y) == 0
         return y[: x.size]
 
     def integrate_wavelet(self, precision=10):

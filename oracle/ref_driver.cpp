@@ -86,6 +86,32 @@ int ref_lfilter_f32_from_f64(const double* b, size_t nb, const double* x, size_t
     });
 }
 
+// lfilter<double> over containers of float: float products, double sum (dsp.hpp:363 with T = double)
+int ref_lfilter_f64_from_f32(const float* b, size_t nb, const float* x, size_t n, double* y) {
+    return guarded([&] {
+        std::vector<float> vb(b, b + nb), vx(x, x + n);
+        const auto r = dsp::lfilter<double>(vb, 1.0, vx);
+        if (!r.empty()) std::memcpy(y, r.data(), r.size() * sizeof(double));
+    });
+}
+
+// lfilter<float> with a recursive part, over containers of float and over containers of double
+int ref_lfilter_f32_iir(const float* b, size_t nb, const float* a, size_t na, const float* x, size_t n, float* y) {
+    return guarded([&] {
+        std::vector<float> vb(b, b + nb), va(a, a + na), vx(x, x + n);
+        const auto r = dsp::lfilter<float>(vb, va, vx);
+        if (!r.empty()) std::memcpy(y, r.data(), r.size() * sizeof(float));
+    });
+}
+
+int ref_lfilter_f32_from_f64_iir(const double* b, size_t nb, const double* a, size_t na, const double* x, size_t n, float* y) {
+    return guarded([&] {
+        std::vector<double> vb(b, b + nb), va(a, a + na), vx(x, x + n);
+        const auto r = dsp::lfilter<float>(vb, va, vx);
+        if (!r.empty()) std::memcpy(y, r.data(), r.size() * sizeof(float));
+    });
+}
+
 int ref_integrate_wavelet(size_t precision, double* psi, double* x) {
     return guarded([&] {
         auto [p, t] = dsp::integrate_wavelet<double>(dsp::cwt_wavelet_t::MORLET, precision);

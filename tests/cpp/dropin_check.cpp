@@ -9,6 +9,9 @@
 //   dropin_check api                                  overloads, ctx reuse, containers, error behaviour
 //   dropin_check cwt <nscales>              < samples integrate_wavelet(MORLET, 10) + cwt over integer scales 1..nscales
 //   dropin_check wavelet <precision>                  integrate_wavelet only (no GPU needed)
+//   dropin_check narrow <b...> / <a...>     < samples the instantiations over narrow element types: lfilter<double> over
+//                                                     vector<float>, lfilter<float> with a recursive part over float and over
+//                                                     double containers (b and a from the command line, "/" between them)
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -74,6 +77,26 @@ int main(int argc, char** argv) {
         // same double taps and data
         auto rf = lfilter<float>(w, 1.0, x);
         dump("yf", std::vector<double>(rf.begin(), rf.end()));
+        return 0;
+    }
+    if (mode == "narrow") {
+        std::vector<double> b, a, x;
+        bool second = false;
+        for (int i = 2; i < argc; ++i) {
+            if (std::strcmp(argv[i], "/") == 0)
+                second = true;
+            else
+                (second ? a : b).push_back(std::strtod(argv[i], nullptr));
+        }
+        std::string tok;
+        while (std::cin >> tok) x.push_back(std::strtod(tok.c_str(), nullptr));
+        const std::vector<float> bf(b.begin(), b.end()), af(a.begin(), a.end()), xf(x.begin(), x.end());
+        dump("f64_from_f32", lfilter<double>(bf, 1.0, xf));         // float products, double sum (dsp.hpp:363, T = double)
+        const auto r1 = lfilter<float>(bf, af, xf);                  // tail in float
+        dump("f32_iir", std::vector<double>(r1.begin(), r1.end()));
+        const auto r2 = lfilter<float>(b, a, x);                     // products and tail in double, float result
+        dump("f32_from_f64_iir", std::vector<double>(r2.begin(), r2.end()));
+        dump("f64_from_f32_iir", lfilter<double>(bf, a, xf));        // float products, double sum, double tail
         return 0;
     }
     if (mode == "wavelet" && argc == 3) {
@@ -177,7 +200,25 @@ int main(int argc, char** argv) {
             lfilter<float>(fctx, wf, std::vector<float>{1.0f}, xf);
             CHECK(fctx.result == want_ff);
             CHECK(lfilter<float>(wf, 1.0f, std::vector<float>{}).empty());
-            CHECK(throws<std::invalid_argument>([&] { lfilter<float>(wf, std::vector<float>{1.0f, -0.5f}, xf); }));
+            // a recursive part in single precision (dsp.hpp:366-368 with T = float): the tail in float, term by term
+            {
+                const std::vector<float> af{2.0f, -0.5f, 0.25f};  // (the first entry is never read)
+                std::vector<float> want = want_ff;
+                for (size_t i = 0; i < want.size(); ++i)
+                    for (size_t j = 1; j < std::min(af.size(), i + 1); ++j) want[i] -= af[j] * want[i - j];
+                CHECK(lfilter<float>(wf, af, xf) == want);
+                CHECK(throws<std::invalid_argument>([&] { lfilter<float>(wf, std::vector<float>(11, 0.1f), xf); }));  // > 8 poles
+            }
+            // lfilter<double> over float containers: float products, double sum (dsp.hpp:363 with T = double)
+            {
+                std::vector<double> want(xf.size());
+                for (size_t i = 0; i < xf.size(); ++i) {
+                    double sum = 0.0;
+                    for (size_t j = 0; j < std::min(wf.size(), i + 1); ++j) sum += static_cast<double>(wf[j] * xf[i - j]);
+                    want[i] = sum;
+                }
+                CHECK(lfilter<double>(wf, 1.0, xf) == want);
+            }
         }
         // empty input -> empty output, empty numerators -> zeros
         CHECK(lfilter<double>(w, 1.0, std::vector<double>{}).empty());

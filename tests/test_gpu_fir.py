@@ -405,3 +405,63 @@ def test_wave_autonomous_form_equals_workgroup_tiled_form(dsp, oracle, torch, nc
                 if lo >= ntaps or h is not None or lo == 0:
                     got = wave[c, lo:hi].cpu().numpy()
                     assert scaled_err(got, ref[:hi - lo]) <= TOL, (c, lo)
+
+
+# ---- narrow element types: lfilter<double> over float containers, lfilter<float> with a recursive part ----
+
+def test_narrow_types_match_reference_outputs(dsp, oracle, golden):
+    """The reference forms numerators[j] * x[i-j] in the type the containers' elements promote to and only then converts
+    to T (dsp.hpp:363); its tail y_i -= denominators[j] * y[i-j] runs in the type denominators[j] * T promotes to
+    (dsp.hpp:367).  Stored outputs of the reference itself, bit for bit, then random cases against the oracle."""
+    x64 = oracle.fill_splitmix(3000, dsp.SEED, 4242)
+    x32 = x64.astype(np.float32)
+    got = dsp.lfilter_f64_from_f32(golden["taps_101_0p25"].astype(np.float32), x32)
+    assert np.array_equal(bits(got), bits(golden["f64_from_f32_y"]))
+    b32, a32 = golden["iir4_b"].astype(np.float32), golden["iir4_a"].astype(np.float32)
+    assert np.array_equal(dsp.lfilter_f32(b32, x32, a=a32).view(np.uint32), golden["f32_iir_y"].view(np.uint32))
+    assert np.array_equal(dsp.lfilter_f32(golden["iir4_b"], x64, a=golden["iir4_a"]).view(np.uint32),
+                          golden["f32_from_f64_iir_y"].view(np.uint32))
+    rng = np.random.default_rng(17)
+    for nb, na, n in ((1, 2, 1), (3, 1, 5000), (40, 9, 2049), (300, 3, 70_001), (7, 5, 4096)):
+        b, x = rng.uniform(-1, 1, nb), rng.uniform(-1, 1, n)
+        a = np.concatenate([[rng.uniform(0.5, 2)], rng.uniform(-0.2, 0.2, na - 1)])
+        bf, af, xf = b.astype(np.float32), a.astype(np.float32), x.astype(np.float32)
+        assert np.array_equal(bits(dsp.lfilter_f64_from_f32(bf, xf)), bits(oracle.lfilter_f64_from_f32(bf, xf))), (nb, n)
+        assert np.array_equal(dsp.lfilter_f32(bf, xf, a=af).view(np.uint32), oracle.lfilter_f32_iir(bf, af, xf).view(np.uint32))
+        assert np.array_equal(dsp.lfilter_f32(b, x, a=a).view(np.uint32), oracle.lfilter_f32_from_f64_iir(b, a, x).view(np.uint32))
+    with pytest.raises(dsp.DspxError, match="at most"):
+        dsp.lfilter_f32(np.ones(2, np.float32), np.ones(10, np.float32), a=np.ones(11, np.float32))
+
+
+def test_cpp_header_narrow_instantiations(dsp, oracle, golden):
+    """The same through include/dsp.hpp, called as a user of the reference would: lfilter<double>(vector<float>, ...),
+    lfilter<float>(b, a, x) over float and over double containers, and lfilter<double> over float taps and samples with
+    double denominators (float products, double sums, double tail)."""
+    import os
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run(["make", "-C", os.path.join(root, "tests", "cpp")], check=True, capture_output=True)
+    b, a = golden["iir4_b"], golden["iir4_a"]
+    x64 = oracle.fill_splitmix(3000, dsp.SEED, 4242)
+    bf, af, xf = b.astype(np.float32), a.astype(np.float32), x64.astype(np.float32)
+    # the program reads the samples as doubles and narrows them itself: hand it the float values
+    inp = "\n".join(float(v).hex() for v in xf.astype(np.float64))
+    args = [float(v).hex() for v in bf.astype(np.float64)] + ["/"] + [float(v).hex() for v in af.astype(np.float64)]
+    r = subprocess.run([os.path.join(root, "tests", "cpp", "dropin_check"), "narrow", *args], input=inp, capture_output=True,
+                       text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    toks, out, i = r.stdout.split(), {}, 0
+    while i < len(toks):
+        name, cnt = toks[i], int(toks[i + 1])
+        out[name] = np.array([float.fromhex(v) for v in toks[i + 2:i + 2 + cnt]])
+        i += 2 + cnt
+    assert np.array_equal(bits(out["f64_from_f32"]), bits(oracle.lfilter_f64_from_f32(bf, xf)))
+    assert np.array_equal(out["f32_iir"].astype(np.float32).view(np.uint32), oracle.lfilter_f32_iir(bf, af, xf).view(np.uint32))
+    wide_b, wide_a, wide_x = bf.astype(np.float64), af.astype(np.float64), xf.astype(np.float64)
+    assert np.array_equal(out["f32_from_f64_iir"].astype(np.float32).view(np.uint32),
+                          oracle.lfilter_f32_from_f64_iir(wide_b, wide_a, wide_x).view(np.uint32))
+    # float products, double sums, double tail: the FIR part of the oracle's float-product form, then its double tail
+    part = oracle.lfilter_f64_from_f32(bf, xf)
+    want = oracle.lfilter([1.0], wide_a, part)
+    assert np.array_equal(bits(out["f64_from_f32_iir"]), bits(want))

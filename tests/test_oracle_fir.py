@@ -166,3 +166,41 @@ def test_fuzz_bit_exact_vs_reference(oracle, reference):
     b64, x64 = rng.standard_normal(40), rng.standard_normal(333)
     assert np.array_equal(oracle.lfilter_f32_from_f64(b64, x64).view(np.uint32),
                           reference.lfilter_f32_from_f64(b64, x64).view(np.uint32))
+
+
+# ---- narrow element types: lfilter<double> over float containers, lfilter<float> with a recursive part ----
+
+def _narrow_inputs(oracle, golden):
+    from oracle.pyoracle import SEED
+
+    x64 = oracle.fill_splitmix(3000, SEED, 4242)
+    return x64.astype(np.float32), x64
+
+
+def test_narrow_types_bit_exact_vs_reference_outputs(oracle, golden):
+    """Stored outputs of the reference's lfilter<double>(vector<float>...) and lfilter<float>(b, a, x) (dsp.hpp:356-369):
+    products in the type the containers' elements promote to, sums and the tail in the types the reference uses."""
+    x32, x64 = _narrow_inputs(oracle, golden)
+    got = oracle.lfilter_f64_from_f32(golden["taps_101_0p25"].astype(np.float32), x32)
+    assert np.array_equal(bits(got), bits(golden["f64_from_f32_y"]))
+    got = oracle.lfilter_f32_iir(golden["iir4_b"].astype(np.float32), golden["iir4_a"].astype(np.float32), x32)
+    assert np.array_equal(got.view(np.uint32), golden["f32_iir_y"].view(np.uint32))
+    got = oracle.lfilter_f32_from_f64_iir(golden["iir4_b"], golden["iir4_a"], x64)
+    assert np.array_equal(got.view(np.uint32), golden["f32_from_f64_iir_y"].view(np.uint32))
+    # the float products really differ from double ones: the same data through lfilter<double> over doubles is elsewhere
+    wide = oracle.lfilter(golden["taps_101_0p25"].astype(np.float32).astype(np.float64), [1.0], x32.astype(np.float64))
+    assert not np.array_equal(bits(wide), bits(golden["f64_from_f32_y"]))
+
+
+def test_narrow_types_fuzz_vs_reference(oracle, reference):
+    rng = np.random.default_rng(5)
+    for _ in range(30):
+        nb, na, n = int(rng.integers(1, 40)), int(rng.integers(1, 7)), int(rng.integers(1, 600))
+        b, x = rng.uniform(-1, 1, nb), rng.uniform(-1, 1, n)
+        a = np.concatenate([[rng.uniform(0.5, 2)], rng.uniform(-0.3, 0.3, na - 1)])
+        b32, a32, x32 = b.astype(np.float32), a.astype(np.float32), x.astype(np.float32)
+        assert np.array_equal(bits(oracle.lfilter_f64_from_f32(b32, x32)), bits(reference.lfilter_f64_from_f32(b32, x32)))
+        assert np.array_equal(oracle.lfilter_f32_iir(b32, a32, x32).view(np.uint32),
+                              reference.lfilter_f32_iir(b32, a32, x32).view(np.uint32))
+        assert np.array_equal(oracle.lfilter_f32_from_f64_iir(b, a, x).view(np.uint32),
+                              reference.lfilter_f32_from_f64_iir(b, a, x).view(np.uint32))
