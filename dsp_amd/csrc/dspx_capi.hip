@@ -1,6 +1,6 @@
 // C ABI of the FIR engine (declared in include/dspx.h): argument checking, the
 // device-resident launch, and the host-pointer paths that move caller memory through
-// pinned staging and device buffers in a four-slot pipeline per GPU.
+// pinned staging and device buffers in an eight-slot pipeline per GPU.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
