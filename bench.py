@@ -648,9 +648,12 @@ def main() -> None:
 
     if rank == 0:
         matrix = not args.exact and not args.vector and numtaps >= dsp_amd.MATRIX_PIPE_MIN_TAPS
-        wave_form = matrix and not args.tiled and (numtaps + 2) // 4 + 1 <= 71   # one window serves the filter (<= 281 taps)
-        kernel_name = ("fir_f64_mfma4w_kernel (v_mfma_f64_4x4x4_4b_f64, wave-autonomous form)" if wave_form else
-                       "fir_f64_mfma4_kernel (v_mfma_f64_4x4x4_4b_f64, workgroup-tiled form)" if matrix else "fir_f64_kernel (v_fma_f64)")
+        steps_of_four = (numtaps + 2) // 4 + 1
+        kernel_name = ("fir_f64_kernel (v_fma_f64)" if not matrix else
+                       "fir_f64_mfma4_kernel (v_mfma_f64_4x4x4_4b_f64, workgroup-tiled form)" if args.tiled else
+                       "fir_f64_mfma4w_kernel (v_mfma_f64_4x4x4_4b_f64, wave-autonomous form, one window per chunk)"
+                       if steps_of_four <= 143 else
+                       "fir_f64_mfma4wm_kernel (v_mfma_f64_4x4x4_4b_f64, wave-autonomous form, several windows per chunk)")
         outputs_per_launch = nchan * n_local
         traffic, traffic_src = (load_traffic(args.workload) if (n_local == n and nchan == WORKLOADS[args.workload][0])
                                 else (None, "this rank's shard is not the profiled launch"))

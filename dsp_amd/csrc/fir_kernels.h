@@ -43,9 +43,9 @@ int fir_bank_stride();  // outputs per workgroup in bank mode
 
 hipError_t launch_fir_f64(const double* taps, const double* x, const double* hist, double* y, const FirShape& shape,
                           bool exact, bool vec2, hipStream_t stream);
-// Matrix-pipe (Toeplitz-block MFMA) variant of launch_fir_f64; tiles are fir_mfma_tile() outputs.  Filters that one
-// window serves (up to 281 taps) over 16-byte aligned buffers run the wave-autonomous form of the kernel unless
-// `tiled` asks for the workgroup-tiled one (same results bit for bit).
+// Matrix-pipe (Toeplitz-block MFMA) variant of launch_fir_f64; tiles are fir_mfma_tile() outputs.  Over 16-byte aligned
+// buffers the wave-autonomous kernels run (one window per chunk up to 569 taps, several beyond) unless `tiled` asks
+// for the workgroup-tiled one (same results bit for bit).
 hipError_t launch_fir_mfma_f64(const double* taps, const double* x, const double* hist, double* y,
                                const FirShape& shape, bool vec2, bool tiled, hipStream_t stream);
 hipError_t launch_fir_mfma_bank_f64(const double* taps, const BankRow* bank, const double* x, double* y,

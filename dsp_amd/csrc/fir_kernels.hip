@@ -835,7 +835,9 @@ __device__ __forceinline__ unsigned long long stamp() {
 }
 #endif
 
-template <int RESIDENT>
+// HG: pad groups of 32 slots in front of the samples of a chunk: 9 (288 slots, filters of up to 281 taps, four
+// workgroups per CU) or 18 (576 slots, up to 569 taps, three workgroups per CU).
+template <int RESIDENT, int HG>
 __global__ __launch_bounds__(kBlock, RESIDENT) void fir_f64_mfma4w_kernel(const double* __restrict__ taps,
                                                                            const double* __restrict__ x,
                                                                            const double* __restrict__ hist,
@@ -843,14 +845,19 @@ __global__ __launch_bounds__(kBlock, RESIDENT) void fir_f64_mfma4w_kernel(const 
     using G = M4Geo<2>;
     constexpr int RB = 8;                                        // row blocks of four outputs per segment
     constexpr int kChunk = G::kWaveOut;                          // outputs per wave and chunk (512)
-    constexpr int kHaloGroups = G::kHalo / G::kSeg;              // 9
-    constexpr int kImgGroups = (G::kHalo + kChunk) / G::kSeg;    // 25 pad groups of 32 slots (34 doubles) per image
+    constexpr int kHaloGroups = HG;
+    constexpr int kHalo = HG * G::kSeg;                          // image slots in front of the chunk (288 / 576)
+    constexpr int kStageSteps = kHalo / 4 - 1;                   // steps the image serves (71 / 143)
+    constexpr int kTapSlots = 4 * kStageSteps + 8;
+    constexpr int kTapIters = (kTapSlots + kBlock - 1) / kBlock;
+    constexpr int kImgGroups = (kHalo + kChunk) / G::kSeg;       // 25 / 34 pad groups of 32 slots (34 doubles) per image
     constexpr int kGroupPairs = G::kPadStep / 2;                 // 17
-    constexpr int kImgPairs = kImgGroups * kGroupPairs;          // 425 pairs = 6800 bytes per wave
-    constexpr int kTapDoubles = (G::kTapSlots + 1) & ~1;
+    constexpr int kImgPairs = kImgGroups * kGroupPairs;          // 425 / 578 pairs = 6800 / 9248 bytes per wave
+    constexpr int kTapDoubles = (kTapSlots + 1) & ~1;
     constexpr int kBodyIters = kChunk / 2 / 64;                  // 16-byte loads per lane and chunk (4)
-    constexpr int kHaloIters = (kHaloGroups * kGroupPairs + 63) / 64;          // 3
-    constexpr int kFirstIters = ((G::kHalo + kChunk) / 2 + 63) / 64;           // 7
+    constexpr int kHaloIters = (kHaloGroups * kGroupPairs + 63) / 64;          // 3 / 5
+    constexpr int kFirstIters = ((kHalo + kChunk) / 2 + 63) / 64;              // 7 / 9
+    static_assert(RESIDENT * (kTapDoubles * 8 + (kBlock / 64) * kImgPairs * 16) <= 160 * 1024, "LDS of the resident workgroups");
     constexpr int kStores = kChunk / 64;                         // 8
     static_assert(kChunk / G::kSeg * G::kOutStep <= (kImgGroups - kHaloGroups) * G::kPadStep,
                   "the transposed results fit in the body's place");
@@ -871,15 +878,15 @@ __global__ __launch_bounds__(kBlock, RESIDENT) void fir_f64_mfma4w_kernel(const 
 
     // tap slot i <- tap i - 3 (zero outside the filter), once per launch
 #pragma unroll
-    for (int r = 0; r < G::kTapIters; ++r) {
+    for (int r = 0; r < kTapIters; ++r) {
         const int i = tid + r * kBlock, j = i - 3;
-        if (i < G::kTapSlots) tapz[i] = (j >= 0 && j < ntaps) ? taps[j] : 0.0;
+        if (i < kTapSlots) tapz[i] = (j >= 0 && j < ntaps) ? taps[j] : 0.0;
     }
     __syncthreads();
 
-    const int steps = (ntaps + 2) / 4 + 1;                                        // <= kStageSteps
-    const int qlo = (G::kHalo - 4 * (steps - 1)) & ~(G::kSeg - 1);                // lowest image slot the products read
-    const int hgroups = (G::kHalo - qlo) / G::kSeg;                               // pad groups of halo in use (1..9)
+    const int steps = (ntaps + 2) / 4 + 1;                                        // <= kStageSteps (the launcher picks HG so)
+    const int qlo = (kHalo - 4 * (steps - 1)) & ~(G::kSeg - 1);                // lowest image slot the products read
+    const int hgroups = (kHalo - qlo) / G::kSeg;                               // pad groups of halo in use (1..9)
     const int hpairs = hgroups * kGroupPairs;
 
     // per-lane LDS addresses, formed once
@@ -930,8 +937,8 @@ __global__ __launch_bounds__(kBlock, RESIDENT) void fir_f64_mfma4w_kernel(const 
         // ---- the run's first window: image slot q <- sample 512*c0 - kHalo + q for q >= qlo ----
         {
             const long long start = (long long)c0 * kChunk;
-            const long long g_lo = start - G::kHalo + qlo;
-            const int npairs = (G::kHalo + kChunk - qlo) / 2;
+            const long long g_lo = start - kHalo + qlo;
+            const int npairs = (kHalo + kChunk - qlo) / 2;
             if (!negative(g_lo) && !negative(n - (start + kChunk))) {
                 const dvec2* src = reinterpret_cast<const dvec2*>(xc + g_lo);
                 dvec2 F[kFirstIters];
@@ -1119,6 +1126,244 @@ __global__ __launch_bounds__(kBlock, RESIDENT) void fir_f64_mfma4w_kernel(const 
 }
 
 // ---------------------------------------------------------------------------------------------
+// The wave-autonomous form for filters that need several windows (more than 281 taps; lfilter mode, 16-byte aligned
+// buffers).  As in fir_f64_mfma4w_kernel every wave is a pipeline of its own -- an LDS image and, here, a tap window
+// of its own, a run of consecutive 512-output chunks, no workgroup barrier -- but a chunk's sums are built from
+// several windows: window w multiplies the tap offsets [4*e0, 4*(e0 + steps)) with the samples that lie 4*e0 further
+// back, so every window brings its own image (there is no halo to carry: the samples come from L2 again, as in the
+// workgroup-tiled kernel, which this form replaces for such filters) and its own 292 tap slots.  While the products
+// of one window run, the samples and taps of the next are in flight into registers; between two windows lies one
+// LDS round trip.  Same products in the same order as fir_f64_mfma4_kernel: same bits.
+template <int RESIDENT>
+__global__ __launch_bounds__(kBlock, RESIDENT) void fir_f64_mfma4wm_kernel(const double* __restrict__ taps,
+                                                                            const double* __restrict__ x,
+                                                                            const double* __restrict__ hist,
+                                                                            double* __restrict__ y, FirShape s, FirRuns rn) {
+    using G = M4Geo<2>;
+    constexpr int RB = 8;
+    constexpr int kChunk = G::kWaveOut;                          // 512
+    constexpr int kHaloGroups = G::kHalo / G::kSeg;              // 9
+    constexpr int kImgGroups = (G::kHalo + kChunk) / G::kSeg;    // 25
+    constexpr int kGroupPairs = G::kPadStep / 2;                 // 17
+    constexpr int kImgPairs = kImgGroups * kGroupPairs;          // 425
+    constexpr int kTapPairs = (G::kTapSlots + 3) / 4 * 2;        // 148 pairs hold the 292 tap slots of a window
+    constexpr int kWinIters = ((G::kHalo + kChunk) / 2 + 63) / 64;   // 16-byte loads per lane and window (7)
+    constexpr int kTapLoads = (G::kTapSlots + 63) / 64;              // 8-byte loads per lane and window (5)
+    constexpr int kStores = kChunk / 64;
+    constexpr int kPairStep = 64 + 64 / 16;
+    constexpr int kBackStep = 64 + 64 / G::kSeg;
+    static_assert(RESIDENT * (kBlock / 64) * (kTapPairs + kImgPairs) * 16 <= 160 * 1024, "LDS of the resident workgroups");
+    __shared__ double2 lds[(kBlock / 64) * (kTapPairs + kImgPairs)];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    double* const tapw = reinterpret_cast<double*>(lds + wave * (kTapPairs + kImgPairs));
+    dvec2* const imgw = reinterpret_cast<dvec2*>(lds + wave * (kTapPairs + kImgPairs) + kTapPairs);
+    double* const imgd = reinterpret_cast<double*>(imgw);
+    const long long n = s.n;
+    const int ntaps = s.ntaps;
+    auto negative = [](long long v) __attribute__((always_inline)) {
+        int hi = (int)((unsigned long long)v >> 32);
+        asm("" : "+s"(hi));
+        return hi < 0;
+    };
+    // steps of four tap offsets cover the band; a window serves up to kStageSteps of them, the windows split them evenly
+    const int total_steps = (ntaps + 2) / 4 + 1;
+    const int nstages = (total_steps + G::kStageSteps - 1) / G::kStageSteps;
+    const int per_stage = (total_steps + nstages - 1) / nstages;
+
+    const double* w_home = imgd + kHaloGroups * G::kPadStep + G::kPadStep * (lane & 15) + (lane >> 4);
+    const double* a_home = tapw + 3 + (lane & 3) - (lane >> 4);
+    double* o_home = imgd + kHaloGroups * G::kPadStep + G::kOutStep * (lane & 15) + (lane >> 4);
+    const double* g_home = imgd + kHaloGroups * G::kPadStep + lane + (lane >> G::kShift);
+    dvec2* const c_home = imgw + lane + (lane >> 4);   // window pair lane + 64 i, counted from slot 0, at c_home[68 i]
+
+    double O[kStores];
+    double* pend_yt = nullptr;
+    int pend_left = 0;
+    bool stores_due = false;
+    auto store_chunk = [&]() __attribute__((always_inline)) {
+        if (pend_left >= kChunk) {
+#pragma unroll
+            for (int j = 0; j < kStores; ++j) __builtin_nontemporal_store(O[j], scalar_base(pend_yt + 64 * j) + (unsigned)lane);
+        } else {
+            const int fl = fresh(lane) & 63;
+#pragma unroll
+            for (int j = 0; j < kStores; ++j)
+                if (fl + 64 * j < pend_left) pend_yt[fl + 64 * j] = O[j];
+        }
+    };
+
+    // ---- the window in flight: image slot q <- sample pos - 4*e0 - kHalo + q (the whole image, whatever part of it
+    // the window's steps read), tap slot i <- tap 4*e0 - 3 + i (zero outside the filter).  A window that reaches
+    // outside the channel, or a tap window that reaches outside the filter, is not fetched ahead: commit() fills it
+    // with range checks.
+    constexpr int kWinPairs = (G::kHalo + kChunk) / 2;   // 400 = 6 * 64 + 16
+    dvec2 R[kWinIters];
+    double T[kTapLoads];
+    bool f_interior = false, f_taps_inside = false;
+    auto fetch = [&](const double* xc, long long pos, int e0) __attribute__((always_inline)) {
+        const long long g_lo = pos - 4 * e0 - G::kHalo;
+        f_interior = !negative(g_lo) && !negative(n - (g_lo + G::kHalo + kChunk));
+        if (f_interior) {
+            const dvec2* src = reinterpret_cast<const dvec2*>(xc + g_lo);
+#pragma unroll
+            for (int i = 0; i < kWinIters; ++i)
+                if (i < kWinIters - 1 || lane < kWinPairs - 64 * (kWinIters - 1)) R[i] = scalar_base(src + 64 * i)[(unsigned)lane];
+        }
+        const int j0 = 4 * e0 - 3;
+        f_taps_inside = j0 >= 0 && j0 + G::kTapSlots <= ntaps;
+        if (f_taps_inside) {
+#pragma unroll
+            for (int r = 0; r < kTapLoads; ++r)
+                if (r < kTapLoads - 1 || lane < G::kTapSlots - 64 * (kTapLoads - 1)) T[r] = scalar_base(taps + j0 + 64 * r)[(unsigned)lane];
+        } else {  // the filter's first and last windows: the nearest tap is fetched, commit() puts zeros where none exists
+            const int fl = fresh(lane) & 63;
+#pragma unroll
+            for (int r = 0; r < kTapLoads; ++r) T[r] = taps[min(max(j0 + fl + 64 * r, 0), ntaps - 1)];
+        }
+    };
+    auto commit = [&](const double* xc, const double* hc, long long pos, int e0) __attribute__((always_inline)) {
+        if (f_interior) {
+#pragma unroll
+            for (int i = 0; i < kWinIters; ++i)
+                if (i < kWinIters - 1 || lane < kWinPairs - 64 * (kWinIters - 1)) c_home[i * kPairStep] = R[i];
+        } else {
+            const long long g_lo = pos - 4 * e0 - G::kHalo;
+#pragma unroll 1
+            for (int p = fresh(lane) & 63; p < kWinPairs; p += 64)
+                imgw[p + (p >> 4)] = dvec2{sample_at(xc, hc, g_lo + 2 * p, n, ntaps), sample_at(xc, hc, g_lo + 2 * p + 1, n, ntaps)};
+        }
+        if (f_taps_inside) {
+#pragma unroll
+            for (int r = 0; r < kTapLoads; ++r)
+                if (r < kTapLoads - 1 || lane < G::kTapSlots - 64 * (kTapLoads - 1)) tapw[lane + 64 * r] = T[r];
+        } else {
+            const int fl = fresh(lane) & 63;
+#pragma unroll
+            for (int r = 0; r < kTapLoads; ++r) {
+                const int i = fl + 64 * r, j = 4 * e0 - 3 + i;
+                if (i < G::kTapSlots) tapw[i] = (unsigned)j < (unsigned)ntaps ? T[r] : 0.0;
+            }
+        }
+        wave_fence();
+    };
+
+    double acc[RB];
+    const unsigned nwaves = gridDim.x * (kBlock / 64);
+    for (unsigned run = blockIdx.x * (kBlock / 64) + wave; run < rn.total_runs; run += nwaves) {
+        const unsigned chan = (unsigned)(((unsigned long long)run * rn.div_magic) >> rn.div_shift);
+        const unsigned c0 = (run - chan * rn.runs_per_chan) * rn.run_chunks;
+        const unsigned c1 = min(c0 + rn.run_chunks, rn.chunks_per_chan);
+        const double* __restrict__ xc = x + (unsigned long long)chan * s.x_stride;
+        const double* __restrict__ hc = hist ? hist + (unsigned long long)chan * s.hist_stride : nullptr;
+        double* yk = y + (unsigned long long)chan * s.y_stride + (unsigned long long)c0 * kChunk;
+
+        // One pass of the loop per window; the window about to be multiplied is (chunk k at `pos`, first step e0).
+        long long pos = (long long)c0 * kChunk;
+        unsigned k = c0;
+        int e0 = 0;
+        fetch(xc, pos, 0);  // the run's first window: waited for on the spot
+        for (;;) {
+            commit(xc, hc, pos, e0);
+            const int steps = min(per_stage, total_steps - e0);
+            const bool last_window = e0 + steps >= total_steps;
+            const bool have_next = !last_window || k + 1 < c1;
+            const long long n_pos = last_window ? pos + kChunk : pos;
+            const int n_e0 = last_window ? 0 : e0 + steps;
+            if (have_next) fetch(xc, n_pos, n_e0);
+            double w[RB];
+#pragma unroll
+            for (int j = 1; j < RB; ++j) w[j] = w_home[4 * (RB - j)];
+            w[0] = w_home[0];
+            const double* wp = w_home - G::kPadStep;
+            const double* ap = a_home;
+            double a_now = ap[0];
+            if (stores_due) store_chunk();
+            stores_due = false;
+            {
+                int el = 0;
+                auto group = [&](auto first) __attribute__((always_inline)) {
+#pragma unroll
+                    for (int u = 0; u < RB; ++u) {
+                        const double a = a_now;
+                        a_now = ap[4 * (u + 1)];
+#pragma unroll
+                        for (int rb = RB - 1; rb >= 0; --rb) {
+                            acc[rb] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, w[(u - rb + RB) % RB], (first.value && u == 0) ? 0.0 : acc[rb], 0, 0, 0);
+                            if (rb == RB - 1) w[(u + 1) % RB] = wp[G::kSeg - 4 * (u + 1)];
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    el += RB, wp -= G::kPadStep, ap += 4 * RB;
+                };
+                if (e0 == 0) {  // a chunk's first step starts its sums from zero
+                    if (steps >= RB) {
+                        group(std::true_type{});
+                    } else {
+#pragma unroll
+                        for (int rb = 0; rb < RB; ++rb) acc[rb] = 0.0;
+                    }
+                }
+                while (el + RB <= steps) group(std::false_type{});
+                if (el < steps) {
+                    const int rem = steps - el;
+#pragma unroll
+                    for (int u = 0; u < RB - 1; ++u) {
+                        if (u < rem) {
+                            const double a = a_now;
+                            a_now = ap[4 * (u + 1)];
+#pragma unroll
+                            for (int rb = RB - 1; rb >= 0; --rb) {
+                                acc[rb] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, w[(u - rb + RB) % RB], acc[rb], 0, 0, 0);
+                                if (rb == RB - 1) w[(u + 1) % RB] = wp[G::kSeg - 4 * (u + 1)];
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                }
+            }
+            wave_fence();
+            if (last_window) {
+                // ---- the chunk is complete: the exactness guard, then the results through the body's place ----
+                unsigned long long any_bad = 0;
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) any_bad |= __builtin_amdgcn_ballot_w64(not_finite(acc[rb]));
+                if (any_bad != 0) {
+#pragma unroll 1
+                    for (int q = fresh(lane) & 63; q < kChunk; q += 64) {
+                        double sum = 0.0;
+                        for (int j = 0; j < ntaps; ++j) {
+                            const long long g = pos + q - j;
+                            if (g >= 0 && g < n)
+                                sum = __builtin_fma(taps[j], xc[g], sum);
+                            else if (g < 0 && hc != nullptr && g >= -(long long)(ntaps - 1))
+                                sum = __builtin_fma(taps[j], hc[(ntaps - 1) + g], sum);
+                        }
+                        imgd[kHaloGroups * G::kPadStep + q + (q >> G::kShift)] = sum;
+                    }
+                } else {
+#pragma unroll
+                    for (int rb = 0; rb < RB; ++rb) o_home[4 * rb] = acc[rb];
+                }
+                wave_fence();
+#pragma unroll
+                for (int j = 0; j < kStores; ++j) O[j] = g_home[j * kBackStep];
+                wave_fence();
+                const long long left = n - pos;
+                pend_yt = yk;
+                pend_left = negative(left - kChunk) ? (int)left : kChunk;
+                stores_due = true;
+                ++k, yk += kChunk;
+            }
+            if (!have_next) break;
+            pos = n_pos, e0 = n_e0;
+        }
+    }
+    if (stores_due) store_chunk();
+}
+
+// ---------------------------------------------------------------------------------------------
 // lfilter over narrow element types (reference dsp.hpp:361-364): the sum has the result type TOUT, and every product
 // is formed in TIN, the type the containers' elements promote to -- float for containers of float, double for
 // containers of double -- converted to TOUT and added, taps ascending.  Separately rounded operations in exactly the
@@ -1267,13 +1512,22 @@ static void launch_mfma_variant(const double* taps, const double* x, const doubl
     const dim3 grid(8 * std::max(per_xcd, 1u)), block(kBlock);
     const bool single = !BANK && shape.ntaps > 0 && (shape.ntaps + 2) / 4 + 1 <= G::kStageSteps;  // one window per tile
     if constexpr (!BANK) {
-        if (single && vec2 && !tiled) {
-            constexpr unsigned kWaves = kBlock / 64, kResident = 4;
-            const unsigned max_waves = compute_units() * kResident * kWaves;
+        if (vec2 && !tiled && shape.ntaps > 0) {
+            // the wave-autonomous forms: one window with a 288-slot halo (up to 281 taps), one window with a 576-slot
+            // halo (up to 569 taps; three workgroups per CU), several windows per chunk beyond that
+            constexpr unsigned kWaves = kBlock / 64;
+            const int steps = (shape.ntaps + 2) / 4 + 1;
+            const unsigned resident = steps <= G::kStageSteps ? 4u : steps <= 2 * G::kStageSteps + 1 ? 3u : 4u;
+            const unsigned max_waves = compute_units() * resident * kWaves;
             FirRuns rn;
             if (plan_runs(shape.total_tiles / shape.tiles_per_chan, shape.n, max_waves, rn)) {
-                const unsigned wgs = std::min((rn.total_runs + kWaves - 1) / kWaves, max_waves / kWaves);
-                hipLaunchKernelGGL((fir_f64_mfma4w_kernel<kResident>), dim3(wgs), block, 0, stream, taps, x, hist, y, shape, rn);
+                const dim3 wgrid(std::min((rn.total_runs + kWaves - 1) / kWaves, max_waves / kWaves));
+                if (steps <= G::kStageSteps)
+                    hipLaunchKernelGGL((fir_f64_mfma4w_kernel<4, 9>), wgrid, block, 0, stream, taps, x, hist, y, shape, rn);
+                else if (steps <= 2 * G::kStageSteps + 1)
+                    hipLaunchKernelGGL((fir_f64_mfma4w_kernel<3, 18>), wgrid, block, 0, stream, taps, x, hist, y, shape, rn);
+                else
+                    hipLaunchKernelGGL((fir_f64_mfma4wm_kernel<4>), wgrid, block, 0, stream, taps, x, hist, y, shape, rn);
                 return;
             }
         }

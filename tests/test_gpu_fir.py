@@ -376,12 +376,18 @@ def test_single_precision_reference_literals(dsp, oracle, literals):
 
 @pytest.mark.parametrize("nchan,n,ntaps", [(1, 513, 101), (3, 5000, 255), (2, 100, 63), (5, 70_001, 57), (300, 2048, 96),
                                            (40, 500_003, 101), (3, (1 << 23) + 5, 255), (1, (1 << 25) + 1000, 63),
-                                           (130, 1 << 18, 160), (1, 1 << 20, 281)])
+                                           (130, 1 << 18, 160), (1, 1 << 20, 281),
+                                           # one window with the 576-slot halo (282 .. 569 taps)
+                                           (1, 513, 282), (3, 5000, 300), (40, 500_003, 320), (2, (1 << 23) + 5, 569),
+                                           # several windows per chunk (570 taps and more)
+                                           (3, 70_001, 570), (5, 70_001, 700), (1, 1 << 20, 1023), (7, 2049, 4095),
+                                           (1, 300, 4095), (1, (1 << 22) + 77, 4095)])
 def test_wave_autonomous_form_equals_workgroup_tiled_form(dsp, oracle, torch, nchan, n, ntaps):
-    """Filters of up to 281 taps over aligned buffers run the wave-autonomous form of the matrix-pipe kernel (every wave
-    walks a run of 512-output chunks and carries its halo in LDS); DSPX_FIR_TILED forces the workgroup-tiled form.
-    Same products in the same order: the same bits -- with and without history, for runs of one chunk (small inputs)
-    and of several (the large ones here), channels that end inside a chunk, and against the oracle on windows."""
+    """Over aligned buffers the matrix pipe runs its wave-autonomous kernels (every wave walks a run of 512-output
+    chunks with an LDS image of its own: one window per chunk and the halo carried in LDS up to 569 taps, several
+    windows per chunk beyond); DSPX_FIR_TILED forces the workgroup-tiled kernel.  Same products in the same order: the
+    same bits -- with and without history, for runs of one chunk (small inputs) and of several (the large ones here),
+    channels that end inside a chunk, and against the oracle on windows."""
     taps_h = dsp.firwin(ntaps, 0.25)
     taps = torch.from_numpy(taps_h).cuda()
     x = torch.empty((nchan, n), dtype=torch.float64, device="cuda")

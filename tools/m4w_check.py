@@ -16,7 +16,10 @@ bad = 0
 rng = np.random.default_rng(7)
 cases = [(1, 512, 101), (1, 513, 101), (3, 5000, 255), (2, 100, 63), (1, 1 << 16, 281), (5, 70001, 57), (64, 1 << 14, 128),
          (1, 1 << 20, 101), (7, 33333, 200), (1, 1, 56), (2, 511, 255), (300, 2048, 96), (1, (1 << 18) + 3, 77),
-         (40, 500_003, 101), (3, (1 << 23) + 5, 255), (1, (1 << 26) + 1000, 63), (130, 1 << 18, 160)]
+         (40, 500_003, 101), (3, (1 << 23) + 5, 255), (1, (1 << 26) + 1000, 63), (130, 1 << 18, 160),
+         (1, 513, 282), (3, 5000, 300), (2, 100, 512), (5, 70_001, 700), (1, 1 << 20, 1023), (1, (1 << 22) + 77, 4095),
+         (40, 500_003, 320), (2, (1 << 23) + 5, 569), (7, 2049, 4095), (1, 300, 4095), (3, 70_001, 570), (64, 1 << 17, 400),
+         (1, (1 << 24) + 3, 283)]
 for minrun in ("default",):
     for nchan, n, nt in cases:
         taps_h = dsp_amd.firwin(nt, 0.25)
