@@ -780,23 +780,26 @@ __global__ __launch_bounds__(kBlock, OB == 4 ? 2 : 4) void fir_f64_mfma4_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
-// Wave-autonomous form of the matrix-pipe kernel for lfilter mode with a filter that one window serves (up to
-// 4 * kStageSteps - 3 = 281 taps) over 16-byte aligned buffers.  Same products, same order, same bits as
-// fir_f64_mfma4_kernel; what differs is who shares what:
-//   * every WAVE has an LDS image of its own (halo + 512 outputs' worth of samples, 6.8 KB) and walks a run of
-//     consecutive 512-output chunks of one channel.  Nothing but the read-only tap table is shared between the waves
-//     of a workgroup, so there is no workgroup barrier after the table has been written: the LDS instructions of one
-//     wave execute in order, which is all the hand-over between a wave's own phases needs;
+// Wave-autonomous form of the matrix-pipe kernel for lfilter mode with a filter that one window serves (up to 569 taps)
+// over 16-byte aligned buffers.  Same products, same order, same bits as fir_f64_mfma4_kernel; what differs is who
+// shares what:
+//   * every WAVE has an LDS image of its own (halo + one chunk of samples: 512 outputs and 288 halo slots in 6.8 KB,
+//     or 1024 outputs and 320 / 576 halo slots in 11.1 / 13.2 KB) and walks a run of consecutive chunks of one
+//     channel.  Nothing but the read-only tap table is shared between the waves of a workgroup, so there is no
+//     workgroup barrier after the table has been written: the LDS instructions of one wave execute in order, which is
+//     all the hand-over between a wave's own phases needs;
 //   * the halo of chunk k + 1 is the tail of chunk k's image: it is read into registers while the products of chunk k
-//     start and written to its new place when they are done (at most three 16-byte reads and writes per lane), so
-//     every sample of a run is fetched from memory exactly once, 64 bytes per lane and chunk (measured: HBM read
-//     traffic within 0.1 % of the algorithmic 8 bytes per output, where the workgroup-tiled form re-reads 11 %);
+//     start and written to its new place when they are done, so every sample of a run is fetched from memory exactly
+//     once, 64 (128) bytes per lane and chunk (measured: HBM read traffic within 0.1 % of the algorithmic 8 bytes per
+//     output, where the workgroup-tiled form re-reads 11 %);
 //   * results are transposed through the body's place in the wave's own image (dead once the products are done),
 //     read back in output order, 512 contiguous bytes per store instruction, and stored one chunk late, after the
 //     next chunk's loads and first LDS reads have been issued.
-// Per chunk a wave issues, besides its matrix instructions, 4 loads, 8 stores, about 30 LDS instructions and about
-// two dozen vector instructions, and waits for nobody but itself: between the last matrix instruction of a chunk and
-// the first of the next lies one LDS round trip.
+// Per chunk a wave issues, besides its matrix instructions, 4 (8) loads, 8 (16) stores, about 30 (45) LDS instructions
+// and about two dozen vector instructions, and waits for nobody but itself: between the last matrix instruction of a
+// chunk and the first of the next lies one LDS round trip.  The 1024-output chunks halve the LDS reads per matrix
+// instruction and the hand-overs per output at the price of two resident workgroups per CU instead of four; they win
+// from 190 taps on.
 //
 // What bounds it (timestamps inside the kernel, tools/m4w_timing.py; builds with the loads or the stores left out):
 // the product loop's marginal cost is exactly its matrix-pipe time, the pipe is occupied 87 % (101 taps) to 95 %
@@ -812,7 +815,7 @@ struct FirRuns {
     unsigned div_shift;
     unsigned runs_per_chan;        // a channel's chunks are cut into this many runs ...
     unsigned run_chunks;           // ... of this many chunks (the last one may be shorter)
-    unsigned chunks_per_chan;      // ceil(n / 512)
+    unsigned chunks_per_chan;      // ceil(n / outputs per chunk)
     unsigned total_runs;           // nchan * runs_per_chan
 };
 
@@ -835,15 +838,17 @@ __device__ __forceinline__ unsigned long long stamp() {
 }
 #endif
 
-// HG: pad groups of 32 slots in front of the samples of a chunk: 9 (288 slots, filters of up to 281 taps, four
-// workgroups per CU) or 18 (576 slots, up to 569 taps, three workgroups per CU).
-template <int RESIDENT, int HG>
+// OB: a segment is 16 * OB consecutive outputs (4 * OB row blocks, one accumulator each), a chunk 16 segments.
+// HG: pad groups (of one segment's length) in front of the samples of a chunk.  <HG 9, OB 2>: 512-output chunks, 288
+// halo slots, four workgroups per CU (116 VGPRs); <5, 4> and <9, 4>: 1024-output chunks, 320 / 576 halo slots (up to
+// 313 / 569 taps), two workgroups per CU (182 / 206 VGPRs).
+template <int RESIDENT, int HG, int OB>
 __global__ __launch_bounds__(kBlock, RESIDENT) void fir_f64_mfma4w_kernel(const double* __restrict__ taps,
                                                                            const double* __restrict__ x,
                                                                            const double* __restrict__ hist,
                                                                            double* __restrict__ y, FirShape s, FirRuns rn) {
-    using G = M4Geo<2>;
-    constexpr int RB = 8;                                        // row blocks of four outputs per segment
+    using G = M4Geo<OB>;
+    constexpr int RB = 4 * OB;                                   // row blocks of four outputs per segment
     constexpr int kChunk = G::kWaveOut;                          // outputs per wave and chunk (512)
     constexpr int kHaloGroups = HG;
     constexpr int kHalo = HG * G::kSeg;                          // image slots in front of the chunk (288 / 576)
@@ -851,7 +856,8 @@ __global__ __launch_bounds__(kBlock, RESIDENT) void fir_f64_mfma4w_kernel(const 
     constexpr int kTapSlots = 4 * kStageSteps + 8;
     constexpr int kTapIters = (kTapSlots + kBlock - 1) / kBlock;
     constexpr int kImgGroups = (kHalo + kChunk) / G::kSeg;       // 25 / 34 pad groups of 32 slots (34 doubles) per image
-    constexpr int kGroupPairs = G::kPadStep / 2;                 // 17
+    constexpr int kGroupPairs = G::kPadStep / 2;                 // 17 (33 for OB = 4)
+    constexpr int kPG = G::kShift - 1;                           // log2 of the sample pairs per group
     constexpr int kImgPairs = kImgGroups * kGroupPairs;          // 425 / 578 pairs = 6800 / 9248 bytes per wave
     constexpr int kTapDoubles = (kTapSlots + 1) & ~1;
     constexpr int kBodyIters = kChunk / 2 / 64;                  // 16-byte loads per lane and chunk (4)
@@ -898,9 +904,9 @@ __global__ __launch_bounds__(kBlock, RESIDENT) void fir_f64_mfma4w_kernel(const 
     constexpr int kBackStep = 64 + 64 / G::kSeg;
     const dvec2* t_src = imgw + (kImgGroups - hgroups) * kGroupPairs + lane;      // halo carry: pair lane + 64 i
     dvec2* t_dst = imgw + (kHaloGroups - hgroups) * kGroupPairs + lane;
-    dvec2* b_dst = imgw + kHaloGroups * kGroupPairs + lane + (lane >> 4);         // body pair lane + 64 i at b_dst[68 i]
-    dvec2* f_dst = imgw + (qlo / G::kSeg) * kGroupPairs + lane + (lane >> 4);     // first window: pair lane + 64 i from qlo
-    constexpr int kPairStep = 64 + 64 / 16;
+    dvec2* b_dst = imgw + kHaloGroups * kGroupPairs + lane + (lane >> kPG);       // body pair lane + 64 i at b_dst[i * kPairStep]
+    dvec2* f_dst = imgw + (qlo / G::kSeg) * kGroupPairs + lane + (lane >> kPG);   // first window: pair lane + 64 i from qlo
+    constexpr int kPairStep = 64 + 128 / G::kSeg;   // image distance of pairs 64 apart (one pad pair per group)
 
     double O[kStores];
     double* pend_yt = nullptr;
@@ -951,7 +957,7 @@ __global__ __launch_bounds__(kBlock, RESIDENT) void fir_f64_mfma4w_kernel(const 
             } else {  // the window reaches outside the channel: every sample range-checked (kept small, not fast)
 #pragma unroll 1
                 for (int p = fresh(lane) & 63; p < npairs; p += 64)
-                    imgw[(qlo / G::kSeg) * kGroupPairs + p + (p >> 4)] =
+                    imgw[(qlo / G::kSeg) * kGroupPairs + p + (p >> kPG)] =
                         dvec2{sample_at(xc, hc, g_lo + 2 * p, n, ntaps), sample_at(xc, hc, g_lo + 2 * p + 1, n, ntaps)};
             }
             wave_fence();
@@ -1098,7 +1104,7 @@ __global__ __launch_bounds__(kBlock, RESIDENT) void fir_f64_mfma4w_kernel(const 
                     const long long pos = (long long)(k + 1) * kChunk;
 #pragma unroll 1
                     for (int p = fresh(lane) & 63; p < kChunk / 2; p += 64)
-                        imgw[kHaloGroups * kGroupPairs + p + (p >> 4)] =
+                        imgw[kHaloGroups * kGroupPairs + p + (p >> kPG)] =
                             dvec2{sample_at(xc, hc, pos + 2 * p, n, ntaps), sample_at(xc, hc, pos + 2 * p + 1, n, ntaps)};
                 }
             }
@@ -1134,23 +1140,24 @@ __global__ __launch_bounds__(kBlock, RESIDENT) void fir_f64_mfma4w_kernel(const 
 // workgroup-tiled kernel, which this form replaces for such filters) and its own 292 tap slots.  While the products
 // of one window run, the samples and taps of the next are in flight into registers; between two windows lies one
 // LDS round trip.  Same products in the same order as fir_f64_mfma4_kernel: same bits.
-template <int RESIDENT>
+template <int RESIDENT, int OB>
 __global__ __launch_bounds__(kBlock, RESIDENT) void fir_f64_mfma4wm_kernel(const double* __restrict__ taps,
                                                                             const double* __restrict__ x,
                                                                             const double* __restrict__ hist,
                                                                             double* __restrict__ y, FirShape s, FirRuns rn) {
-    using G = M4Geo<2>;
-    constexpr int RB = 8;
-    constexpr int kChunk = G::kWaveOut;                          // 512
-    constexpr int kHaloGroups = G::kHalo / G::kSeg;              // 9
-    constexpr int kImgGroups = (G::kHalo + kChunk) / G::kSeg;    // 25
-    constexpr int kGroupPairs = G::kPadStep / 2;                 // 17
-    constexpr int kImgPairs = kImgGroups * kGroupPairs;          // 425
-    constexpr int kTapPairs = (G::kTapSlots + 3) / 4 * 2;        // 148 pairs hold the 292 tap slots of a window
-    constexpr int kWinIters = ((G::kHalo + kChunk) / 2 + 63) / 64;   // 16-byte loads per lane and window (7)
-    constexpr int kTapLoads = (G::kTapSlots + 63) / 64;              // 8-byte loads per lane and window (5)
+    using G = M4Geo<OB>;                                         // OB = 2: 512-output chunks, 288 halo slots; 4: 1024, 320
+    constexpr int RB = 4 * OB;
+    constexpr int kChunk = G::kWaveOut;                          // 512 / 1024
+    constexpr int kHaloGroups = G::kHalo / G::kSeg;              // 9 / 5
+    constexpr int kImgGroups = (G::kHalo + kChunk) / G::kSeg;    // 25 / 21
+    constexpr int kGroupPairs = G::kPadStep / 2;                 // 17 / 33
+    constexpr int kPG = G::kShift - 1;                           // log2 of the sample pairs per group
+    constexpr int kImgPairs = kImgGroups * kGroupPairs;          // 425 / 693
+    constexpr int kTapPairs = (G::kTapSlots + 3) / 4 * 2;        // pairs that hold the 292 / 324 tap slots of a window
+    constexpr int kWinIters = ((G::kHalo + kChunk) / 2 + 63) / 64;   // 16-byte loads per lane and window (7 / 11)
+    constexpr int kTapLoads = (G::kTapSlots + 63) / 64;              // 8-byte loads per lane and window (5 / 6)
     constexpr int kStores = kChunk / 64;
-    constexpr int kPairStep = 64 + 64 / 16;
+    constexpr int kPairStep = 64 + 128 / G::kSeg;                // image distance of pairs 64 apart
     constexpr int kBackStep = 64 + 64 / G::kSeg;
     static_assert(RESIDENT * (kBlock / 64) * (kTapPairs + kImgPairs) * 16 <= 160 * 1024, "LDS of the resident workgroups");
     __shared__ double2 lds[(kBlock / 64) * (kTapPairs + kImgPairs)];
@@ -1176,7 +1183,7 @@ __global__ __launch_bounds__(kBlock, RESIDENT) void fir_f64_mfma4wm_kernel(const
     const double* a_home = tapw + 3 + (lane & 3) - (lane >> 4);
     double* o_home = imgd + kHaloGroups * G::kPadStep + G::kOutStep * (lane & 15) + (lane >> 4);
     const double* g_home = imgd + kHaloGroups * G::kPadStep + lane + (lane >> G::kShift);
-    dvec2* const c_home = imgw + lane + (lane >> 4);   // window pair lane + 64 i, counted from slot 0, at c_home[68 i]
+    dvec2* const c_home = imgw + lane + (lane >> kPG);   // window pair lane + 64 i, counted from slot 0, at c_home[i * kPairStep]
 
     double O[kStores];
     double* pend_yt = nullptr;
@@ -1198,7 +1205,7 @@ __global__ __launch_bounds__(kBlock, RESIDENT) void fir_f64_mfma4wm_kernel(const
     // the window's steps read), tap slot i <- tap 4*e0 - 3 + i (zero outside the filter).  A window that reaches
     // outside the channel, or a tap window that reaches outside the filter, is not fetched ahead: commit() fills it
     // with range checks.
-    constexpr int kWinPairs = (G::kHalo + kChunk) / 2;   // 400 = 6 * 64 + 16
+    constexpr int kWinPairs = (G::kHalo + kChunk) / 2;   // 400 = 6 * 64 + 16 (672 = 10 * 64 + 32)
     dvec2 R[kWinIters];
     double T[kTapLoads];
     bool f_interior = false, f_taps_inside = false;
@@ -1232,7 +1239,7 @@ __global__ __launch_bounds__(kBlock, RESIDENT) void fir_f64_mfma4wm_kernel(const
             const long long g_lo = pos - 4 * e0 - G::kHalo;
 #pragma unroll 1
             for (int p = fresh(lane) & 63; p < kWinPairs; p += 64)
-                imgw[p + (p >> 4)] = dvec2{sample_at(xc, hc, g_lo + 2 * p, n, ntaps), sample_at(xc, hc, g_lo + 2 * p + 1, n, ntaps)};
+                imgw[p + (p >> kPG)] = dvec2{sample_at(xc, hc, g_lo + 2 * p, n, ntaps), sample_at(xc, hc, g_lo + 2 * p + 1, n, ntaps)};
         }
         if (f_taps_inside) {
 #pragma unroll
@@ -1479,12 +1486,12 @@ static unsigned compute_units() {
     return cached[dev] = (unsigned)cus;
 }
 
-// Cuts `nchan` channels of `n` samples into runs of consecutive 512-output chunks for the wave-autonomous kernel: a
+// Cuts `nchan` channels of `n` samples into runs of consecutive chunks of `kChunk` outputs for the wave-autonomous kernels: a
 // run never crosses a channel; with a large input there are about kRunsPerWave runs per resident wave, so that the
 // waves end together, and never fewer than kMinRun chunks per run unless the input is too small to occupy every
 // wave that way (a run's first window is fetched with its halo, the only samples read twice).
-static bool plan_runs(unsigned nchan, long long n, unsigned max_waves, FirRuns& rn) {
-    constexpr unsigned long long kChunk = M4Geo<kMatrixOB>::kWaveOut, kRunsPerWave = 8, kMinRun = 32;
+static bool plan_runs(unsigned nchan, long long n, unsigned max_waves, FirRuns& rn, unsigned long long kChunk) {
+    constexpr unsigned long long kRunsPerWave = 8, kMinRun = 32;
     const unsigned long long cpc = ((unsigned long long)n + kChunk - 1) / kChunk, total_chunks = cpc * nchan;
     unsigned long long want = (total_chunks + kRunsPerWave * max_waves - 1) / (kRunsPerWave * max_waves);
     if (want < kMinRun) want = std::min(kMinRun, std::max<unsigned long long>(1, total_chunks / max_waves));
@@ -1513,21 +1520,26 @@ static void launch_mfma_variant(const double* taps, const double* x, const doubl
     const bool single = !BANK && shape.ntaps > 0 && (shape.ntaps + 2) / 4 + 1 <= G::kStageSteps;  // one window per tile
     if constexpr (!BANK) {
         if (vec2 && !tiled && shape.ntaps > 0) {
-            // the wave-autonomous forms: one window with a 288-slot halo (up to 281 taps), one window with a 576-slot
-            // halo (up to 569 taps; three workgroups per CU), several windows per chunk beyond that
+            // The wave-autonomous forms (measured on one box, tools/tap_sweep.py): up to 189 taps 512-output chunks with
+            // a 288-slot halo, four workgroups per CU; up to 569 taps 1024-output chunks (half the LDS reads per matrix
+            // instruction, half the chunk hand-overs) with a 320- or 576-slot halo, two workgroups per CU; beyond that
+            // several windows per 512-output chunk.
             constexpr unsigned kWaves = kBlock / 64;
+            constexpr int kBigFrom = 49;   // steps of four tap offsets from which the 1024-output chunks win (190 taps)
             const int steps = (shape.ntaps + 2) / 4 + 1;
-            const unsigned resident = steps <= G::kStageSteps ? 4u : steps <= 2 * G::kStageSteps + 1 ? 3u : 4u;
-            const unsigned max_waves = compute_units() * resident * kWaves;
+            const bool big = steps >= kBigFrom && steps <= 2 * M4Geo<2>::kStageSteps + 1;
+            const unsigned max_waves = compute_units() * (big ? 2u : 4u) * kWaves;
             FirRuns rn;
-            if (plan_runs(shape.total_tiles / shape.tiles_per_chan, shape.n, max_waves, rn)) {
+            if (plan_runs(shape.total_tiles / shape.tiles_per_chan, shape.n, max_waves, rn, big ? 1024 : 512)) {
                 const dim3 wgrid(std::min((rn.total_runs + kWaves - 1) / kWaves, max_waves / kWaves));
-                if (steps <= G::kStageSteps)
-                    hipLaunchKernelGGL((fir_f64_mfma4w_kernel<4, 9>), wgrid, block, 0, stream, taps, x, hist, y, shape, rn);
-                else if (steps <= 2 * G::kStageSteps + 1)
-                    hipLaunchKernelGGL((fir_f64_mfma4w_kernel<3, 18>), wgrid, block, 0, stream, taps, x, hist, y, shape, rn);
+                if (steps < kBigFrom)
+                    hipLaunchKernelGGL((fir_f64_mfma4w_kernel<4, 9, 2>), wgrid, block, 0, stream, taps, x, hist, y, shape, rn);
+                else if (steps <= M4Geo<4>::kStageSteps)
+                    hipLaunchKernelGGL((fir_f64_mfma4w_kernel<2, 5, 4>), wgrid, block, 0, stream, taps, x, hist, y, shape, rn);
+                else if (big)
+                    hipLaunchKernelGGL((fir_f64_mfma4w_kernel<2, 9, 4>), wgrid, block, 0, stream, taps, x, hist, y, shape, rn);
                 else
-                    hipLaunchKernelGGL((fir_f64_mfma4wm_kernel<4>), wgrid, block, 0, stream, taps, x, hist, y, shape, rn);
+                    hipLaunchKernelGGL((fir_f64_mfma4wm_kernel<4, 2>), wgrid, block, 0, stream, taps, x, hist, y, shape, rn);
                 return;
             }
         }
