@@ -1257,28 +1257,62 @@ __global__ __launch_bounds__(kBlock, RESIDENT) void fir_f64_mfma4wm_kernel(const
     };
 
     double acc[RB];
-    const unsigned nwaves = gridDim.x * (kBlock / 64);
-    for (unsigned run = blockIdx.x * (kBlock / 64) + wave; run < rn.total_runs; run += nwaves) {
-        const unsigned chan = (unsigned)(((unsigned long long)run * rn.div_magic) >> rn.div_shift);
-        const unsigned c0 = (run - chan * rn.runs_per_chan) * rn.run_chunks;
-        const unsigned c1 = min(c0 + rn.run_chunks, rn.chunks_per_chan);
-        const double* __restrict__ xc = x + (unsigned long long)chan * s.x_stride;
-        const double* __restrict__ hc = hist ? hist + (unsigned long long)chan * s.hist_stride : nullptr;
-        double* yk = y + (unsigned long long)chan * s.y_stride + (unsigned long long)c0 * kChunk;
-
-        // One pass of the loop per window; the window about to be multiplied is (chunk k at `pos`, first step e0).
-        long long pos = (long long)c0 * kChunk;
-        unsigned k = c0;
+    // Blocks b and b + 8 share an XCD and its L2.  A chunk's windows slide back over ntaps + chunk samples, which the
+    // chunks next to it read as well: the waves of an XCD therefore take ADJACENT runs at the same time (the grid is a
+    // multiple of 8 workgroups, the launcher keeps the runs short), so that what one wave fetched is found in that
+    // XCD's L2 by its neighbours, and the XCD moves on to its next stretch of the input as a whole.
+    const unsigned xcd = blockIdx.x % 8, in_xcd = (blockIdx.x / 8) * (kBlock / 64) + wave, per_xcd = gridDim.x / 8 * (kBlock / 64);
+    // A wave's place among its XCD's waves moves on by one with every stretch: the chunks at the start of a channel
+    // cost more (their windows are filled from the history, synchronously), and with channels a power of two long a
+    // fixed place would hand all of them to the same few waves, which the rest of the chip then waits for.
+    // The last stretch is usually a partial one: its runs are dealt round-robin over the XCDs instead, so that what is
+    // left (all there is, for a small input) is spread over the whole chip and not over the first XCDs only.
+    const unsigned per_stretch = 8 * per_xcd;
+    auto run_at = [&](unsigned first, unsigned pl) __attribute__((always_inline)) {
+        return first + per_stretch > rn.total_runs ? first + in_xcd * 8 + xcd : first + xcd * per_xcd + pl;
+    };
+    unsigned stretch = 0, place = in_xcd;  // `stretch`: the first run of the stretch the wave is in
+    unsigned run = run_at(stretch, place);
+    if (run < rn.total_runs) {
+        const double *xc, *hc;
+        double* yk;
+        long long pos;
+        unsigned left_in_run;   // chunks of the run after the current one
+        auto locate = [&](unsigned r, const double*& cx, const double*& ch, double*& cy, long long& cpos, unsigned& more)
+                          __attribute__((always_inline)) {
+            const unsigned chan = (unsigned)(((unsigned long long)r * rn.div_magic) >> rn.div_shift);
+            const unsigned c0 = (r - chan * rn.runs_per_chan) * rn.run_chunks;
+            more = min(c0 + rn.run_chunks, rn.chunks_per_chan) - c0 - 1;
+            cpos = (long long)c0 * kChunk;
+            cx = x + (unsigned long long)chan * s.x_stride;
+            ch = hist ? hist + (unsigned long long)chan * s.hist_stride : nullptr;
+            cy = y + (unsigned long long)chan * s.y_stride + cpos;
+        };
+        locate(run, xc, hc, yk, pos, left_in_run);
+        // One pass of the loop per window; the window about to be multiplied is (the chunk at `pos`, first step e0).
         int e0 = 0;
-        fetch(xc, pos, 0);  // the run's first window: waited for on the spot
+        fetch(xc, pos, 0);  // the wave's first window: waited for on the spot
         for (;;) {
             commit(xc, hc, pos, e0);
             const int steps = min(per_stage, total_steps - e0);
             const bool last_window = e0 + steps >= total_steps;
-            const bool have_next = !last_window || k + 1 < c1;
-            const long long n_pos = last_window ? pos + kChunk : pos;
-            const int n_e0 = last_window ? 0 : e0 + steps;
-            if (have_next) fetch(xc, n_pos, n_e0);
+            // the window after this one: the chunk's next, the first of the run's next chunk, or of the wave's next run
+            const unsigned next_place = place + 1 == per_xcd ? 0 : place + 1;
+            const unsigned next_run = run_at(stretch + per_stretch, next_place);
+            const bool have_next = !last_window || left_in_run > 0 || next_run < rn.total_runs;
+            const double *n_xc = xc, *n_hc = hc;
+            double* n_yk = yk;
+            long long n_pos = pos;
+            unsigned n_left = left_in_run;
+            int n_e0 = e0 + steps;
+            if (last_window && have_next) {
+                n_e0 = 0;
+                if (left_in_run > 0)
+                    n_pos = pos + kChunk, n_yk = yk + kChunk, n_left = left_in_run - 1;
+                else
+                    locate(next_run, n_xc, n_hc, n_yk, n_pos, n_left);
+            }
+            if (have_next) fetch(n_xc, n_pos, n_e0);
             double w[RB];
 #pragma unroll
             for (int j = 1; j < RB; ++j) w[j] = w_home[4 * (RB - j)];
@@ -1361,10 +1395,10 @@ __global__ __launch_bounds__(kBlock, RESIDENT) void fir_f64_mfma4wm_kernel(const
                 pend_yt = yk;
                 pend_left = negative(left - kChunk) ? (int)left : kChunk;
                 stores_due = true;
-                ++k, yk += kChunk;
+                if (left_in_run == 0) run = next_run, stretch += per_stretch, place = next_place;
             }
             if (!have_next) break;
-            pos = n_pos, e0 = n_e0;
+            xc = n_xc, hc = n_hc, yk = n_yk, pos = n_pos, left_in_run = n_left, e0 = n_e0;
         }
     }
     if (stores_due) store_chunk();
@@ -1490,11 +1524,13 @@ static unsigned compute_units() {
 // run never crosses a channel; with a large input there are about kRunsPerWave runs per resident wave, so that the
 // waves end together, and never fewer than kMinRun chunks per run unless the input is too small to occupy every
 // wave that way (a run's first window is fetched with its halo, the only samples read twice).
-static bool plan_runs(unsigned nchan, long long n, unsigned max_waves, FirRuns& rn, unsigned long long kChunk) {
+static bool plan_runs(unsigned nchan, long long n, unsigned max_waves, FirRuns& rn, unsigned long long kChunk,
+                      unsigned long long fixed_run = 0) {
     constexpr unsigned long long kRunsPerWave = 8, kMinRun = 32;
     const unsigned long long cpc = ((unsigned long long)n + kChunk - 1) / kChunk, total_chunks = cpc * nchan;
     unsigned long long want = (total_chunks + kRunsPerWave * max_waves - 1) / (kRunsPerWave * max_waves);
     if (want < kMinRun) want = std::min(kMinRun, std::max<unsigned long long>(1, total_chunks / max_waves));
+    if (fixed_run) want = fixed_run;   // (a kernel that carries nothing from chunk to chunk)
     want = std::min(want, cpc);
     rn = FirRuns{};
     rn.chunks_per_chan = (unsigned)cpc;
@@ -1530,8 +1566,11 @@ static void launch_mfma_variant(const double* taps, const double* x, const doubl
             const bool big = steps >= kBigFrom && steps <= 2 * M4Geo<2>::kStageSteps + 1;
             const unsigned max_waves = compute_units() * (big ? 2u : 4u) * kWaves;
             FirRuns rn;
-            if (plan_runs(shape.total_tiles / shape.tiles_per_chan, shape.n, max_waves, rn, big ? 1024 : 512)) {
-                const dim3 wgrid(std::min((rn.total_runs + kWaves - 1) / kWaves, max_waves / kWaves));
+            const bool several = steps > 2 * M4Geo<2>::kStageSteps + 1;   // several windows per chunk: runs of one chunk
+            if (plan_runs(shape.total_tiles / shape.tiles_per_chan, shape.n, max_waves, rn, big ? 1024 : 512, several ? 1 : 0)) {
+                unsigned wgs = std::min((rn.total_runs + kWaves - 1) / kWaves, max_waves / kWaves);
+                if (several) wgs = (wgs + 7) / 8 * 8;   // (its waves are addressed by XCD)
+                const dim3 wgrid(wgs);
                 if (steps < kBigFrom)
                     hipLaunchKernelGGL((fir_f64_mfma4w_kernel<4, 9, 2>), wgrid, block, 0, stream, taps, x, hist, y, shape, rn);
                 else if (steps <= M4Geo<4>::kStageSteps)
