@@ -28,6 +28,12 @@ for nm in sys.argv[1:] or ["l101"]:
     assert fn(buf.ctypes.data, buf.size) == 0
     t = buf.reshape(-1, 16)
     t = t[t[:, 3] > 0]
+    # Waves of the last launch only: a launch with fewer waves leaves the higher slots of an earlier one untouched.  The
+    # cycle counters of the XCDs are not aligned with each other, so "recent" is judged per XCD.
+    xcc = (t[:, 6].astype(np.int64) >> 32) & 15
+    newest = np.zeros(16, dtype=np.uint64)
+    np.maximum.at(newest, xcc, t[:, 4])
+    t = t[t[:, 4].astype(np.int64) >= newest[xcc].astype(np.int64) - 1_000_000]
     prod, probe, rest, nch, t0, t1, hw, real, t64 = [t[:, i].astype(np.float64) for i in range(9)]
     hwi = t[:, 6].astype(np.int64) & 0xffffffff
     simd = (hwi >> 4) & 3
@@ -36,7 +42,8 @@ for nm in sys.argv[1:] or ["l101"]:
     se = (hwi >> 13) & 7
     xc = (t[:, 6].astype(np.int64) >> 32) & 15
     steps = (nt + 2) // 4 + 1
-    print(f"== {nm}: {len(t)} waves, {nch.mean():.1f} chunks per wave, {steps} steps = {steps * 8 * 16} pipe cycles per chunk")
+    rb = 16 if 49 <= steps <= 143 else 8   # matrix instructions per step: 1024-output chunks from 190 to 569 taps
+    print(f"== {nm}: {len(t)} waves, {nch.mean():.1f} chunks of {64 * rb} outputs per wave, {steps} steps = {steps * rb * 16} pipe cycles per chunk")
     print(f"   per chunk (mean over waves, s_memtime ticks): products {np.mean(prod / nch):8.0f}  probe {np.mean(probe / nch):7.0f}  "
           f"rest {np.mean(rest / nch):7.0f}   wave lifetime {np.mean(t1 - t0):.0f}, span {(t1.max() - t0.min()):.0f}")
     print(f"   clock: {np.mean((t1 - t0) / real) * 0.1:.3f} GHz (s_memtime ticks per 10 ns of s_memrealtime), kernel {real.max() * 1e-5:.3f} ms")
@@ -54,6 +61,6 @@ for nm in sys.argv[1:] or ["l101"]:
         m = ranks == r
         print(f"   wave #{r} of its SIMD ({m.sum():5d} waves): products {np.mean(prod[m] / nch[m]):8.0f}  probe {np.mean(probe[m] / nch[m]):7.0f}  "
               f"rest {np.mean(rest[m] / nch[m]):7.0f}  lifetime {np.mean((t1 - t0)[m]):9.0f}  first 64 chunks {np.mean((t64 - t0)[m & (t64 > 0)]) / 64:8.0f} per chunk")
-    share = sum(steps * 128 / (np.mean((t64 - t0)[(ranks == r) & (t64 > 0)]) / 64) for r in range(ranks.max() + 1))
+    share = sum(steps * rb * 16 / (np.mean((t64 - t0)[(ranks == r) & (t64 > 0)]) / 64) for r in range(ranks.max() + 1))
     print(f"   matrix pipe share while all waves run (first 64 chunks): {share:.3f}")
     print(f"   SIMDs seen: {len(np.unique(key))}, waves per SIMD: {np.bincount(np.unique(key, return_inverse=True)[1]).mean():.2f}")

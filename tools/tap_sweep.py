@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Tap-count sweep of the FIR kernels on one box, one process: vector pipe, matrix pipe (the default form: wave-autonomous
-up to 281 taps) and the matrix pipe's workgroup-tiled form, device-resident, 2048 x 2^20 samples unless the row names a
+at every tap count) and the matrix pipe's workgroup-tiled form, device-resident, 2048 x 2^20 samples unless the row names a
 benchmark configuration.  Writes JSON (the crossover between the pipes, kMatrixPipeMinTaps, is read off this table).
    python tools/tap_sweep.py [out.json]"""
 import json
