@@ -1132,14 +1132,18 @@ __global__ __launch_bounds__(kBlock, RESIDENT) void fir_f64_mfma4w_kernel(const 
 }
 
 // ---------------------------------------------------------------------------------------------
-// The wave-autonomous form for filters that need several windows (more than 281 taps; lfilter mode, 16-byte aligned
+// The wave-autonomous form for filters that need several windows (more than 569 taps; lfilter mode, 16-byte aligned
 // buffers).  As in fir_f64_mfma4w_kernel every wave is a pipeline of its own -- an LDS image and, here, a tap window
-// of its own, a run of consecutive 512-output chunks, no workgroup barrier -- but a chunk's sums are built from
-// several windows: window w multiplies the tap offsets [4*e0, 4*(e0 + steps)) with the samples that lie 4*e0 further
-// back, so every window brings its own image (there is no halo to carry: the samples come from L2 again, as in the
-// workgroup-tiled kernel, which this form replaces for such filters) and its own 292 tap slots.  While the products
-// of one window run, the samples and taps of the next are in flight into registers; between two windows lies one
-// LDS round trip.  Same products in the same order as fir_f64_mfma4_kernel: same bits.
+// of its own, 512-output chunks, no workgroup barrier -- but a chunk's sums are built from several windows: window w
+// multiplies the tap offsets [4*e0, 4*(e0 + steps)) with the samples that lie 4*e0 further back, so every window
+// brings its own image and its own 292 tap slots.  There is no halo to carry; a sample is read by every window that
+// slides over it, (ntaps + 512) / 284 windows per chunk, and what keeps those reads out of HBM is the order in which
+// the chunks are taken: the waves of an XCD work on adjacent chunks at the same time, so all but the first read of a
+// sample are hits in that XCD's L2 (measured at 4095 taps over one stream: HBM reads 1.05 x the algorithmic 8 bytes
+// per output; 12.8 x when every wave walked a run of consecutive chunks of its own).  While the products of one
+// window run, the samples and taps of the next -- the next chunk's first window after a chunk's last -- are in flight
+// into registers; between two windows lies one LDS round trip.  Same products in the same order as
+// fir_f64_mfma4_kernel: same bits.
 template <int RESIDENT, int OB>
 __global__ __launch_bounds__(kBlock, RESIDENT) void fir_f64_mfma4wm_kernel(const double* __restrict__ taps,
                                                                             const double* __restrict__ x,
@@ -1259,7 +1263,7 @@ __global__ __launch_bounds__(kBlock, RESIDENT) void fir_f64_mfma4wm_kernel(const
     double acc[RB];
     // Blocks b and b + 8 share an XCD and its L2.  A chunk's windows slide back over ntaps + chunk samples, which the
     // chunks next to it read as well: the waves of an XCD therefore take ADJACENT runs at the same time (the grid is a
-    // multiple of 8 workgroups, the launcher keeps the runs short), so that what one wave fetched is found in that
+    // multiple of 8 workgroups; the launcher makes a run one chunk), so that what one wave fetched is found in that
     // XCD's L2 by its neighbours, and the XCD moves on to its next stretch of the input as a whole.
     const unsigned xcd = blockIdx.x % 8, in_xcd = (blockIdx.x / 8) * (kBlock / 64) + wave, per_xcd = gridDim.x / 8 * (kBlock / 64);
     // A wave's place among its XCD's waves moves on by one with every stretch: the chunks at the start of a channel
