@@ -29,11 +29,12 @@ for nm in sys.argv[1:] or ["l101"]:
     t = buf.reshape(-1, 16)
     t = t[t[:, 3] > 0]
     # Waves of the last launch only: a launch with fewer waves leaves the higher slots of an earlier one untouched.  The
-    # cycle counters of the XCDs are not aligned with each other, so "recent" is judged per XCD.
-    xcc = (t[:, 6].astype(np.int64) >> 32) & 15
-    newest = np.zeros(16, dtype=np.uint64)
-    np.maximum.at(newest, xcc, t[:, 4])
-    t = t[t[:, 4].astype(np.int64) >= newest[xcc].astype(np.int64) - 1_000_000]
+    # cycle counters of different parts of the chip are not aligned with each other, so "recent" is judged per CU.
+    hw = t[:, 6].astype(np.int64)
+    where = ((((hw >> 32) & 15) * 8 + ((hw >> 13) & 7)) * 2 + ((hw >> 12) & 1)) * 16 + ((hw >> 8) & 15)
+    newest = np.zeros(where.max() + 1, dtype=np.int64)
+    np.maximum.at(newest, where, t[:, 4].astype(np.int64))
+    t = t[t[:, 4].astype(np.int64) >= newest[where] - 1_000_000]
     prod, probe, rest, nch, t0, t1, hw, real, t64 = [t[:, i].astype(np.float64) for i in range(9)]
     hwi = t[:, 6].astype(np.int64) & 0xffffffff
     simd = (hwi >> 4) & 3
