@@ -381,7 +381,9 @@ def test_single_precision_reference_literals(dsp, oracle, literals):
                                            (1, 513, 282), (3, 5000, 300), (40, 500_003, 320), (2, (1 << 23) + 5, 569),
                                            # several windows per chunk (570 taps and more)
                                            (3, 70_001, 570), (5, 70_001, 700), (1, 1 << 20, 1023), (7, 2049, 4095),
-                                           (1, 300, 4095), (1, (1 << 22) + 77, 4095)])
+                                           (1, 300, 4095), (1, (1 << 22) + 77, 4095),
+                                           # ... over several stretches of the chip's resident waves, channels ending inside them
+                                           (3, 3_000_001, 600), (5000, 1000, 570)])
 def test_wave_autonomous_form_equals_workgroup_tiled_form(dsp, oracle, torch, nchan, n, ntaps):
     """Over aligned buffers the matrix pipe runs its wave-autonomous kernels (every wave walks a run of 512-output
     chunks with an LDS image of its own: one window per chunk and the halo carried in LDS up to 569 taps, several

@@ -19,7 +19,7 @@ cases = [(1, 512, 101), (1, 513, 101), (3, 5000, 255), (2, 100, 63), (1, 1 << 16
          (40, 500_003, 101), (3, (1 << 23) + 5, 255), (1, (1 << 26) + 1000, 63), (130, 1 << 18, 160),
          (1, 513, 282), (3, 5000, 300), (2, 100, 512), (5, 70_001, 700), (1, 1 << 20, 1023), (1, (1 << 22) + 77, 4095),
          (40, 500_003, 320), (2, (1 << 23) + 5, 569), (7, 2049, 4095), (1, 300, 4095), (3, 70_001, 570), (64, 1 << 17, 400),
-         (1, (1 << 24) + 3, 283)]
+         (1, (1 << 24) + 3, 283), (3, 3_000_001, 600), (5000, 1000, 570)]
 for minrun in ("default",):
     for nchan, n, nt in cases:
         taps_h = dsp_amd.firwin(nt, 0.25)
