@@ -163,13 +163,13 @@ def run_cwt(args, rank, world, dev, dist, red_dev, ranks_seen=1):
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        bank.apply(sig, out=out, exact=args.exact, mfma=False if args.vector else None)
+        bank.apply(sig, out=out, exact=args.exact, mfma=False if args.vector else None, tiled=args.tiled)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     fence()
     t0 = time.perf_counter()
     ev[0].record()
     for i in range(args.steps):
-        bank.apply(sig, out=out, exact=args.exact, mfma=False if args.vector else None)
+        bank.apply(sig, out=out, exact=args.exact, mfma=False if args.vector else None, tiled=args.tiled)
         ev[i + 1].record()
     fence()
     dt = time.perf_counter() - t0
@@ -181,6 +181,8 @@ def run_cwt(args, rank, world, dev, dist, red_dev, ranks_seen=1):
         return
     dt_max, kern_ms = float(t[0]), float(t[1])
     traffic, traffic_src = load_traffic("cwt65")
+    if args.tiled or args.vector or args.exact:
+        traffic, traffic_src = None, "the profiled figure belongs to the default kernels"
     flops = 2.0 * bank.total_taps * n            # 2 * 34385 per input sample
     bytes_alg = (8.0 + 8.0 * nscales) * n        # read once, one output row per scale
     sec = kern_ms / 1e3
@@ -194,7 +196,8 @@ def run_cwt(args, rank, world, dev, dist, red_dev, ranks_seen=1):
         "roofline": {"bound": "mfma", "achieved": flops / sec / 1e12, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
                      "frac": flops / sec / 1e12 / PEAK_FP64_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                      "kernel": "fir_f64_kernel (bank mode, vector pipe)" if args.vector or args.exact else
-                               "fir_f64_mfma4_kernel + fir_f64_kernel (bank mode; rows of >= 56 taps on the matrix pipe)",
+                               ("fir_f64_mfma4_kernel" if args.tiled else "fir_f64_mfma4wm_kernel (wave-autonomous form)") +
+                               " + fir_f64_kernel (bank mode; rows of >= 56 taps on the matrix pipe)",
                      "kernel_ms": kern_ms,
                      "note": "FP64 FMA; algorithmic flops = 2 * sum of per-scale tap counts per input sample"},
         "roofline_other": {"bound": "hbm", "achieved": bytes_alg / sec / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",

@@ -226,17 +226,18 @@ def integrate_wavelet(precision: int = 10, lower: float = -8.0, upper: float = 8
     return psi, x
 
 
-def cwt(signal, scales, psi, wx, exact: bool = False, ngpus=None, mfma=None) -> np.ndarray:
-    """dsp::cwt(signal, scales, psi, x) for host arrays -> (len(scales), len(signal)), rows by ascending scale."""
+def cwt(signal, scales, psi, wx, exact: bool = False, ngpus=None, mfma=None, tiled: bool = False) -> np.ndarray:
+    """dsp::cwt(signal, scales, psi, x) for host arrays -> (len(scales), len(signal)), rows by ascending scale.
+    tiled: the workgroup-tiled form of the matrix-pipe kernel (for comparison measurements; results differ in rounding)."""
     signal, scales, psi, wx = _np_f64(signal), _np_f64(np.atleast_1d(scales)), _np_f64(psi), _np_f64(wx)
     out = np.empty((scales.size, signal.size), dtype=np.float64)
     if ngpus is None:
         rc = lib().dspx_cwt_f64(signal.ctypes.data, signal.size, scales.ctypes.data, scales.size, psi.ctypes.data,
-                                psi.size, wx.ctypes.data, wx.size, out.ctypes.data, _flags(exact, mfma))
+                                psi.size, wx.ctypes.data, wx.size, out.ctypes.data, _flags(exact, mfma, tiled))
     else:
         rc = lib().dspx_cwt_f64_multi(signal.ctypes.data, signal.size, scales.ctypes.data, scales.size,
                                       psi.ctypes.data, psi.size, wx.ctypes.data, wx.size, out.ctypes.data, int(ngpus),
-                                      _flags(exact, mfma))
+                                      _flags(exact, mfma, tiled))
     check(rc)
     return out
 
@@ -263,7 +264,7 @@ class CwtBank:
         self.rows = int(lib().dspx_cwt_bank_rows(h))
         self.total_taps = int(lib().dspx_cwt_bank_total_taps(h))
 
-    def apply(self, signal, out=None, exact: bool = False, mfma=None):
+    def apply(self, signal, out=None, exact: bool = False, mfma=None, tiled: bool = False):
         import torch
 
         assert signal.is_cuda and signal.dtype == torch.float64 and signal.dim() == 1 and signal.is_contiguous()
@@ -271,7 +272,7 @@ class CwtBank:
             out = torch.empty((self.rows, signal.numel()), dtype=torch.float64, device=signal.device)
         assert out.shape == (self.rows, signal.numel()) and out.stride(1) == 1
         check(lib().dspx_cwt_bank_apply_dev(self._h, signal.data_ptr(), signal.numel(), out.data_ptr(), out.stride(0),
-                                            _flags(exact, mfma), _stream_ptr()))
+                                            _flags(exact, mfma, tiled), _stream_ptr()))
         return out
 
     def close(self):

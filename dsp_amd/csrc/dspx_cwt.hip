@@ -126,6 +126,7 @@ int make_bank(const Tables& t, const double* psi, const std::vector<size_t>& pic
         d.ntaps = (int)len;
         // c[t] = sum_k h[k] * x[t - k]; kept sample i is the difference c[start+i+1] - c[start+i]
         d.advance = (int)r.start;
+        d.win_steps = dspx::fir_mfma_window_steps(d.ntaps);
         for (size_t k = 0; k < len; ++k) taps.push_back(psi[r.index[len - 1 - k]]);
         if (taps.size() & 1) taps.push_back(0.0);  // keep every row's taps 16-byte aligned
         rows.push_back(d);
@@ -191,7 +192,7 @@ int apply_bank(const dspx_cwt_bank* bank, const double* d_signal, size_t n, doub
             dspx::set_divider(s, (unsigned)run);
             if (mfma)
                 DSPX_HIP(dspx::launch_fir_mfma_bank_f64(bank->d_taps, bank->d_rows + first + r0, d_signal, d_result,
-                                                        s, vec2, stream));
+                                                        s, vec2, (flags & DSPX_FIR_TILED) != 0, stream));
             else
                 DSPX_HIP(dspx::launch_fir_bank_f64(bank->d_taps, bank->d_rows + first + r0, d_signal, d_result, s,
                                                    (flags & DSPX_FIR_EXACT) != 0, vec2, stream));

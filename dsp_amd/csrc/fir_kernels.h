@@ -34,6 +34,7 @@ struct BankRow {
     double scale;
     int ntaps;
     int advance;
+    int win_steps;  // fir_mfma_window_steps(ntaps): the steps of four tap offsets one window of the matrix-pipe kernels serves
 };
 
 int fir_tile();         // outputs per workgroup
@@ -48,8 +49,12 @@ hipError_t launch_fir_f64(const double* taps, const double* x, const double* his
 // for the workgroup-tiled one (same results bit for bit).
 hipError_t launch_fir_mfma_f64(const double* taps, const double* x, const double* hist, double* y,
                                const FirShape& shape, bool vec2, bool tiled, hipStream_t stream);
+// Bank mode on the matrix pipe: the wave-autonomous kernel (510-output chunks of a row; aligned or not) unless `tiled`
+// asks for the workgroup-tiled one (2046-output tiles).  The two chunkings group a row's taps differently, so their
+// results differ in rounding; a row's bits depend on neither the other rows nor the alignment of the buffers.
 hipError_t launch_fir_mfma_bank_f64(const double* taps, const BankRow* bank, const double* x, double* y,
-                                    const FirShape& shape, bool vec2, hipStream_t stream);
+                                    const FirShape& shape, bool vec2, bool tiled, hipStream_t stream);
+int fir_mfma_window_steps(int ntaps);  // for BankRow::win_steps
 // Bank mode: shape.n = length of the single input and of every output row, shape.y_stride = elements
 // between output rows, shape.tiles_per_chan = ceil(n / fir_bank_stride()), shape.total_tiles =
 // rows * 8 * ceil(tiles_per_chan / 8) workgroups (each row is cut into 8 runs of tiles, one per XCD; the

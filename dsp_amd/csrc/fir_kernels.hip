@@ -1144,14 +1144,26 @@ __global__ __launch_bounds__(kBlock, RESIDENT) void fir_f64_mfma4w_kernel(const 
 // window run, the samples and taps of the next -- the next chunk's first window after a chunk's last -- are in flight
 // into registers; between two windows lies one LDS round trip.  Same products in the same order as
 // fir_f64_mfma4_kernel: same bits.
-template <int RESIDENT, int OB>
+//
+// BANK (the wavelet path, reference dsp.hpp:1136-1217): one input, rows of taps of different lengths.  A unit of work is
+// a chunk of one row: 512 values of c[t] = sum_k taps_r[k] * x[t + advance_r - k] (zeros outside [0, n)), of which the
+// first 510 leave as (c[i+1] - c[i]) * scale_r -- the first difference, the scaling and the crop fused into the
+// read-back, as in the workgroup-tiled kernel; a chunk advances by 510 outputs so that the c[i+1] (c[i+2] when the
+// row's advance is odd and was rounded down to keep the windows 16-byte aligned) of its last output is its own.  Rows
+// come longest first; the waves of the chip work through them together, row after row, so they all meet chunks of
+// the same cost at the same time.  VEC2 = false reads the windows with 8-byte loads (a signal that is only 8-byte
+// aligned); everything else is the same, so a row's bits do not depend on the alignment of the buffers.
+template <int RESIDENT, int OB, bool BANK, bool VEC2>
 __global__ __launch_bounds__(kBlock, RESIDENT) void fir_f64_mfma4wm_kernel(const double* __restrict__ taps,
                                                                             const double* __restrict__ x,
                                                                             const double* __restrict__ hist,
-                                                                            double* __restrict__ y, FirShape s, FirRuns rn) {
+                                                                            double* __restrict__ y,
+                                                                            const BankRow* __restrict__ bank, FirShape s,
+                                                                            FirRuns rn) {
     using G = M4Geo<OB>;                                         // OB = 2: 512-output chunks, 288 halo slots; 4: 1024, 320
     constexpr int RB = 4 * OB;
-    constexpr int kChunk = G::kWaveOut;                          // 512 / 1024
+    constexpr int kChunk = G::kWaveOut;                          // values per chunk: 512 / 1024
+    constexpr int kOutputs = BANK ? kChunk - 2 : kChunk;         // outputs a chunk stores (and advances by)
     constexpr int kHaloGroups = G::kHalo / G::kSeg;              // 9 / 5
     constexpr int kImgGroups = (G::kHalo + kChunk) / G::kSeg;    // 25 / 21
     constexpr int kGroupPairs = G::kPadStep / 2;                 // 17 / 33
@@ -1164,6 +1176,8 @@ __global__ __launch_bounds__(kBlock, RESIDENT) void fir_f64_mfma4wm_kernel(const
     constexpr int kPairStep = 64 + 128 / G::kSeg;                // image distance of pairs 64 apart
     constexpr int kBackStep = 64 + 64 / G::kSeg;
     static_assert(RESIDENT * (kBlock / 64) * (kTapPairs + kImgPairs) * 16 <= 160 * 1024, "LDS of the resident workgroups");
+    static_assert(!BANK || (kChunk + 1) + ((kChunk + 1) >> G::kShift) < (kImgGroups - kHaloGroups) * G::kPadStep,
+                  "bank mode reads c[q + 2] of a chunk's last values inside the image");
     __shared__ double2 lds[(kBlock / 64) * (kTapPairs + kImgPairs)];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1172,21 +1186,34 @@ __global__ __launch_bounds__(kBlock, RESIDENT) void fir_f64_mfma4wm_kernel(const
     dvec2* const imgw = reinterpret_cast<dvec2*>(lds + wave * (kTapPairs + kImgPairs) + kTapPairs);
     double* const imgd = reinterpret_cast<double*>(imgw);
     const long long n = s.n;
-    const int ntaps = s.ntaps;
     auto negative = [](long long v) __attribute__((always_inline)) {
         int hi = (int)((unsigned long long)v >> 32);
         asm("" : "+s"(hi));
         return hi < 0;
     };
-    // steps of four tap offsets cover the band; a window serves up to kStageSteps of them, the windows split them evenly
-    const int total_steps = (ntaps + 2) / 4 + 1;
-    const int nstages = (total_steps + G::kStageSteps - 1) / G::kStageSteps;
-    const int per_stage = (total_steps + nstages - 1) / nstages;
+    // The filter of a chunk.  Steps of four tap offsets cover its band; a window serves up to kStageSteps of them, the
+    // windows split them evenly (bank mode: the host has done that division per row).
+    struct Filter {
+        const double* tc;  // its taps
+        double post;       // bank mode: the factor on the first difference
+        int ntaps, odd;    // bank mode: whether the row's advance was rounded down
+        int total_steps, per_stage;
+    };
+    Filter cur{};
+    cur.tc = taps, cur.post = 1.0, cur.ntaps = s.ntaps, cur.odd = 0;
+    cur.total_steps = (s.ntaps + 2) / 4 + 1;
+    {
+        const int nstages = (cur.total_steps + G::kStageSteps - 1) / G::kStageSteps;
+        cur.per_stage = (cur.total_steps + nstages - 1) / nstages;
+    }
+    Filter nxt = cur;  // (lfilter mode: one filter per launch, never written again)
 
     const double* w_home = imgd + kHaloGroups * G::kPadStep + G::kPadStep * (lane & 15) + (lane >> 4);
     const double* a_home = tapw + 3 + (lane & 3) - (lane >> 4);
     double* o_home = imgd + kHaloGroups * G::kPadStep + G::kOutStep * (lane & 15) + (lane >> 4);
     const double* g_home = imgd + kHaloGroups * G::kPadStep + lane + (lane >> G::kShift);
+    const double* g_home1 = imgd + kHaloGroups * G::kPadStep + (lane + 1) + ((lane + 1) >> G::kShift);   // bank mode: values lane + 1, + 2
+    const double* g_home2 = imgd + kHaloGroups * G::kPadStep + (lane + 2) + ((lane + 2) >> G::kShift);
     dvec2* const c_home = imgw + lane + (lane >> kPG);   // window pair lane + 64 i, counted from slot 0, at c_home[i * kPairStep]
 
     double O[kStores];
@@ -1194,9 +1221,11 @@ __global__ __launch_bounds__(kBlock, RESIDENT) void fir_f64_mfma4wm_kernel(const
     int pend_left = 0;
     bool stores_due = false;
     auto store_chunk = [&]() __attribute__((always_inline)) {
-        if (pend_left >= kChunk) {
+        if (pend_left >= kOutputs) {
 #pragma unroll
-            for (int j = 0; j < kStores; ++j) __builtin_nontemporal_store(O[j], scalar_base(pend_yt + 64 * j) + (unsigned)lane);
+            for (int j = 0; j < kStores; ++j)
+                if (!BANK || j < kStores - 1 || lane < 64 - (kChunk - kOutputs))
+                    __builtin_nontemporal_store(O[j], scalar_base(pend_yt + 64 * j) + (unsigned)lane);
         } else {
             const int fl = fresh(lane) & 63;
 #pragma unroll
@@ -1213,28 +1242,35 @@ __global__ __launch_bounds__(kBlock, RESIDENT) void fir_f64_mfma4wm_kernel(const
     dvec2 R[kWinIters];
     double T[kTapLoads];
     bool f_interior = false, f_taps_inside = false;
-    auto fetch = [&](const double* xc, long long pos, int e0) __attribute__((always_inline)) {
+    auto fetch = [&](const Filter& f, const double* xc, long long pos, int e0) __attribute__((always_inline)) {
         const long long g_lo = pos - 4 * e0 - G::kHalo;
         f_interior = !negative(g_lo) && !negative(n - (g_lo + G::kHalo + kChunk));
         if (f_interior) {
-            const dvec2* src = reinterpret_cast<const dvec2*>(xc + g_lo);
 #pragma unroll
-            for (int i = 0; i < kWinIters; ++i)
-                if (i < kWinIters - 1 || lane < kWinPairs - 64 * (kWinIters - 1)) R[i] = scalar_base(src + 64 * i)[(unsigned)lane];
+            for (int i = 0; i < kWinIters; ++i) {
+                if (i < kWinIters - 1 || lane < kWinPairs - 64 * (kWinIters - 1)) {
+                    if constexpr (VEC2) {
+                        R[i] = scalar_base(reinterpret_cast<const dvec2*>(xc + g_lo) + 64 * i)[(unsigned)lane];
+                    } else {
+                        const auto p = scalar_base(xc + g_lo + 128 * i);
+                        R[i] = dvec2{p[2u * (unsigned)lane], p[2u * (unsigned)lane + 1u]};
+                    }
+                }
+            }
         }
         const int j0 = 4 * e0 - 3;
-        f_taps_inside = j0 >= 0 && j0 + G::kTapSlots <= ntaps;
+        f_taps_inside = j0 >= 0 && j0 + G::kTapSlots <= f.ntaps;
         if (f_taps_inside) {
 #pragma unroll
             for (int r = 0; r < kTapLoads; ++r)
-                if (r < kTapLoads - 1 || lane < G::kTapSlots - 64 * (kTapLoads - 1)) T[r] = scalar_base(taps + j0 + 64 * r)[(unsigned)lane];
+                if (r < kTapLoads - 1 || lane < G::kTapSlots - 64 * (kTapLoads - 1)) T[r] = scalar_base(f.tc + j0 + 64 * r)[(unsigned)lane];
         } else {  // the filter's first and last windows: the nearest tap is fetched, commit() puts zeros where none exists
             const int fl = fresh(lane) & 63;
 #pragma unroll
-            for (int r = 0; r < kTapLoads; ++r) T[r] = taps[min(max(j0 + fl + 64 * r, 0), ntaps - 1)];
+            for (int r = 0; r < kTapLoads; ++r) T[r] = f.tc[min(max(j0 + fl + 64 * r, 0), f.ntaps - 1)];
         }
     };
-    auto commit = [&](const double* xc, const double* hc, long long pos, int e0) __attribute__((always_inline)) {
+    auto commit = [&](const Filter& f, const double* xc, const double* hc, long long pos, int e0) __attribute__((always_inline)) {
         if (f_interior) {
 #pragma unroll
             for (int i = 0; i < kWinIters; ++i)
@@ -1243,7 +1279,7 @@ __global__ __launch_bounds__(kBlock, RESIDENT) void fir_f64_mfma4wm_kernel(const
             const long long g_lo = pos - 4 * e0 - G::kHalo;
 #pragma unroll 1
             for (int p = fresh(lane) & 63; p < kWinPairs; p += 64)
-                imgw[p + (p >> kPG)] = dvec2{sample_at(xc, hc, g_lo + 2 * p, n, ntaps), sample_at(xc, hc, g_lo + 2 * p + 1, n, ntaps)};
+                imgw[p + (p >> kPG)] = dvec2{sample_at(xc, hc, g_lo + 2 * p, n, f.ntaps), sample_at(xc, hc, g_lo + 2 * p + 1, n, f.ntaps)};
         }
         if (f_taps_inside) {
 #pragma unroll
@@ -1254,7 +1290,7 @@ __global__ __launch_bounds__(kBlock, RESIDENT) void fir_f64_mfma4wm_kernel(const
 #pragma unroll
             for (int r = 0; r < kTapLoads; ++r) {
                 const int i = fl + 64 * r, j = 4 * e0 - 3 + i;
-                if (i < G::kTapSlots) tapw[i] = (unsigned)j < (unsigned)ntaps ? T[r] : 0.0;
+                if (i < G::kTapSlots) tapw[i] = (unsigned)j < (unsigned)f.ntaps ? T[r] : 0.0;
             }
         }
         wave_fence();
@@ -1278,45 +1314,58 @@ __global__ __launch_bounds__(kBlock, RESIDENT) void fir_f64_mfma4wm_kernel(const
     unsigned stretch = 0, place = in_xcd;  // `stretch`: the first run of the stretch the wave is in
     unsigned run = run_at(stretch, place);
     if (run < rn.total_runs) {
+        // The chunk in hand: its channel (row), `pos` = the sample position of its first value, `yk` / `opos` = where its
+        // first output goes and which output of the channel that is.
         const double *xc, *hc;
         double* yk;
-        long long pos;
+        long long pos, opos;
         unsigned left_in_run;   // chunks of the run after the current one
-        auto locate = [&](unsigned r, const double*& cx, const double*& ch, double*& cy, long long& cpos, unsigned& more)
-                          __attribute__((always_inline)) {
+        auto locate = [&](unsigned r, Filter& f, const double*& cx, const double*& ch, double*& cy, long long& cpos,
+                          long long& copos, unsigned& more) __attribute__((always_inline)) {
             const unsigned chan = (unsigned)(((unsigned long long)r * rn.div_magic) >> rn.div_shift);
             const unsigned c0 = (r - chan * rn.runs_per_chan) * rn.run_chunks;
             more = min(c0 + rn.run_chunks, rn.chunks_per_chan) - c0 - 1;
-            cpos = (long long)c0 * kChunk;
-            cx = x + (unsigned long long)chan * s.x_stride;
-            ch = hist ? hist + (unsigned long long)chan * s.hist_stride : nullptr;
-            cy = y + (unsigned long long)chan * s.y_stride + cpos;
+            copos = (long long)c0 * kOutputs;
+            if constexpr (BANK) {
+                const BankRow row = bank[chan];
+                f.tc = taps + row.taps_off, f.post = row.scale, f.ntaps = row.ntaps, f.odd = row.advance & 1;
+                f.total_steps = (row.ntaps + 2) / 4 + 1, f.per_stage = row.win_steps;
+                cpos = copos + row.advance - f.odd;
+                cx = x, ch = nullptr;
+                cy = y + row.out_off * s.y_stride + copos;
+            } else {
+                cpos = copos;
+                cx = x + (unsigned long long)chan * s.x_stride;
+                ch = hist ? hist + (unsigned long long)chan * s.hist_stride : nullptr;
+                cy = y + (unsigned long long)chan * s.y_stride + copos;
+            }
         };
-        locate(run, xc, hc, yk, pos, left_in_run);
+        locate(run, cur, xc, hc, yk, pos, opos, left_in_run);
         // One pass of the loop per window; the window about to be multiplied is (the chunk at `pos`, first step e0).
         int e0 = 0;
-        fetch(xc, pos, 0);  // the wave's first window: waited for on the spot
+        fetch(cur, xc, pos, 0);  // the wave's first window: waited for on the spot
         for (;;) {
-            commit(xc, hc, pos, e0);
-            const int steps = min(per_stage, total_steps - e0);
-            const bool last_window = e0 + steps >= total_steps;
+            commit(cur, xc, hc, pos, e0);
+            const int steps = min(cur.per_stage, cur.total_steps - e0);
+            const bool last_window = e0 + steps >= cur.total_steps;
             // the window after this one: the chunk's next, the first of the run's next chunk, or of the wave's next run
             const unsigned next_place = place + 1 == per_xcd ? 0 : place + 1;
             const unsigned next_run = run_at(stretch + per_stretch, next_place);
             const bool have_next = !last_window || left_in_run > 0 || next_run < rn.total_runs;
             const double *n_xc = xc, *n_hc = hc;
             double* n_yk = yk;
-            long long n_pos = pos;
+            long long n_pos = pos, n_opos = opos;
             unsigned n_left = left_in_run;
             int n_e0 = e0 + steps;
+            if constexpr (BANK) nxt = cur;
             if (last_window && have_next) {
                 n_e0 = 0;
                 if (left_in_run > 0)
-                    n_pos = pos + kChunk, n_yk = yk + kChunk, n_left = left_in_run - 1;
+                    n_pos = pos + kOutputs, n_opos = opos + kOutputs, n_yk = yk + kOutputs, n_left = left_in_run - 1;
                 else
-                    locate(next_run, n_xc, n_hc, n_yk, n_pos, n_left);
+                    locate(next_run, nxt, n_xc, n_hc, n_yk, n_pos, n_opos, n_left);
             }
-            if (have_next) fetch(n_xc, n_pos, n_e0);
+            if (have_next) fetch(BANK ? nxt : cur, n_xc, n_pos, n_e0);
             double w[RB];
 #pragma unroll
             for (int j = 1; j < RB; ++j) w[j] = w_home[4 * (RB - j)];
@@ -1378,12 +1427,12 @@ __global__ __launch_bounds__(kBlock, RESIDENT) void fir_f64_mfma4wm_kernel(const
 #pragma unroll 1
                     for (int q = fresh(lane) & 63; q < kChunk; q += 64) {
                         double sum = 0.0;
-                        for (int j = 0; j < ntaps; ++j) {
+                        for (int j = 0; j < cur.ntaps; ++j) {
                             const long long g = pos + q - j;
                             if (g >= 0 && g < n)
-                                sum = __builtin_fma(taps[j], xc[g], sum);
-                            else if (g < 0 && hc != nullptr && g >= -(long long)(ntaps - 1))
-                                sum = __builtin_fma(taps[j], hc[(ntaps - 1) + g], sum);
+                                sum = __builtin_fma(cur.tc[j], xc[g], sum);
+                            else if (g < 0 && hc != nullptr && g >= -(long long)(cur.ntaps - 1))
+                                sum = __builtin_fma(cur.tc[j], hc[(cur.ntaps - 1) + g], sum);
                         }
                         imgd[kHaloGroups * G::kPadStep + q + (q >> G::kShift)] = sum;
                     }
@@ -1392,17 +1441,30 @@ __global__ __launch_bounds__(kBlock, RESIDENT) void fir_f64_mfma4wm_kernel(const
                     for (int rb = 0; rb < RB; ++rb) o_home[4 * rb] = acc[rb];
                 }
                 wave_fence();
+                if constexpr (BANK) {
+                    // (c[q+1] - c[q]) * factor, shifted by one when the advance was rounded down (wave-uniform); the last
+                    // two lanes of the last read form values that are never stored
+                    if (cur.odd) {
 #pragma unroll
-                for (int j = 0; j < kStores; ++j) O[j] = g_home[j * kBackStep];
+                        for (int j = 0; j < kStores; ++j) O[j] = (g_home2[j * kBackStep] - g_home1[j * kBackStep]) * cur.post;
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < kStores; ++j) O[j] = (g_home1[j * kBackStep] - g_home[j * kBackStep]) * cur.post;
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < kStores; ++j) O[j] = g_home[j * kBackStep];
+                }
                 wave_fence();
-                const long long left = n - pos;
+                const long long left = n - opos;
                 pend_yt = yk;
-                pend_left = negative(left - kChunk) ? (int)left : kChunk;
+                pend_left = negative(left - kOutputs) ? (int)left : kOutputs;
                 stores_due = true;
                 if (left_in_run == 0) run = next_run, stretch += per_stretch, place = next_place;
             }
             if (!have_next) break;
-            xc = n_xc, hc = n_hc, yk = n_yk, pos = n_pos, left_in_run = n_left, e0 = n_e0;
+            xc = n_xc, hc = n_hc, yk = n_yk, pos = n_pos, opos = n_opos, left_in_run = n_left, e0 = n_e0;
+            if constexpr (BANK) cur = nxt;
         }
     }
     if (stores_due) store_chunk();
@@ -1558,20 +1620,39 @@ static void launch_mfma_variant(const double* taps, const double* x, const doubl
     const unsigned per_xcd = std::min((shape.total_tiles + 7) / 8, compute_units() * G::kResident / 8);
     const dim3 grid(8 * std::max(per_xcd, 1u)), block(kBlock);
     const bool single = !BANK && shape.ntaps > 0 && (shape.ntaps + 2) / 4 + 1 <= G::kStageSteps;  // one window per tile
+    if constexpr (BANK) {
+        // The wave-autonomous form: a unit of work is a 510-output chunk of one row; the positions of the tiled form's
+        // walk (rows * 8 runs of tiles) give the number of rows back.
+        const unsigned tile_run = (shape.tiles_per_chan + 7) / 8;
+        const unsigned rows = tile_run ? shape.total_tiles / (8 * tile_run) : 0;
+        constexpr unsigned kWaves = kBlock / 64;
+        const unsigned max_waves = compute_units() * 4u * kWaves;
+        FirRuns rn;
+        if (!tiled && rows > 0 && plan_runs(rows, shape.n, max_waves, rn, M4Geo<2>::kWaveOut - 2, 1)) {
+            const unsigned wgs = (std::min((rn.total_runs + kWaves - 1) / kWaves, max_waves / kWaves) + 7) / 8 * 8;
+            if (vec2)
+                hipLaunchKernelGGL((fir_f64_mfma4wm_kernel<4, 2, true, true>), dim3(wgs), block, 0, stream, taps, x, hist, y, bank, shape, rn);
+            else
+                hipLaunchKernelGGL((fir_f64_mfma4wm_kernel<4, 2, true, false>), dim3(wgs), block, 0, stream, taps, x, hist, y, bank, shape, rn);
+            return;
+        }
+    }
     if constexpr (!BANK) {
         if (vec2 && !tiled && shape.ntaps > 0) {
             // The wave-autonomous forms (measured on one box, tools/tap_sweep.py): up to 189 taps 512-output chunks with
             // a 288-slot halo, four workgroups per CU; up to 569 taps 1024-output chunks (half the LDS reads per matrix
             // instruction, half the chunk hand-overs) with a 320- or 576-slot halo, two workgroups per CU; beyond that
-            // several windows per 512-output chunk.
+            // several windows per 512-output chunk (per 1024-output chunk while two of its longer windows suffice:
+            // +3 % at 570 taps, where the smaller chunk needs three; no gain for longer filters).
             constexpr unsigned kWaves = kBlock / 64;
             constexpr int kBigFrom = 49;   // steps of four tap offsets from which the 1024-output chunks win (190 taps)
             const int steps = (shape.ntaps + 2) / 4 + 1;
             const bool big = steps >= kBigFrom && steps <= 2 * M4Geo<2>::kStageSteps + 1;
-            const unsigned max_waves = compute_units() * (big ? 2u : 4u) * kWaves;
-            FirRuns rn;
             const bool several = steps > 2 * M4Geo<2>::kStageSteps + 1;   // several windows per chunk: runs of one chunk
-            if (plan_runs(shape.total_tiles / shape.tiles_per_chan, shape.n, max_waves, rn, big ? 1024 : 512, several ? 1 : 0)) {
+            const bool wm4 = several && steps <= 2 * M4Geo<4>::kStageSteps;  // ... two windows of 1024-output chunks (570-629 taps)
+            const unsigned max_waves = compute_units() * ((big || wm4) ? 2u : 4u) * kWaves;
+            FirRuns rn;
+            if (plan_runs(shape.total_tiles / shape.tiles_per_chan, shape.n, max_waves, rn, (big || wm4) ? 1024 : 512, several ? 1 : 0)) {
                 unsigned wgs = std::min((rn.total_runs + kWaves - 1) / kWaves, max_waves / kWaves);
                 if (several) wgs = (wgs + 7) / 8 * 8;   // (its waves are addressed by XCD)
                 const dim3 wgrid(wgs);
@@ -1581,8 +1662,10 @@ static void launch_mfma_variant(const double* taps, const double* x, const doubl
                     hipLaunchKernelGGL((fir_f64_mfma4w_kernel<2, 5, 4>), wgrid, block, 0, stream, taps, x, hist, y, shape, rn);
                 else if (big)
                     hipLaunchKernelGGL((fir_f64_mfma4w_kernel<2, 9, 4>), wgrid, block, 0, stream, taps, x, hist, y, shape, rn);
+                else if (wm4)
+                    hipLaunchKernelGGL((fir_f64_mfma4wm_kernel<2, 4, false, true>), wgrid, block, 0, stream, taps, x, hist, y, bank, shape, rn);
                 else
-                    hipLaunchKernelGGL((fir_f64_mfma4wm_kernel<4, 2>), wgrid, block, 0, stream, taps, x, hist, y, shape, rn);
+                    hipLaunchKernelGGL((fir_f64_mfma4wm_kernel<4, 2, false, true>), wgrid, block, 0, stream, taps, x, hist, y, bank, shape, rn);
                 return;
             }
         }
@@ -1608,10 +1691,17 @@ hipError_t launch_fir_mfma_f64(const double* taps, const double* x, const double
 }
 
 hipError_t launch_fir_mfma_bank_f64(const double* taps, const BankRow* bank, const double* x, double* y,
-                                    const FirShape& shape, bool vec2, hipStream_t stream) {
+                                    const FirShape& shape, bool vec2, bool tiled, hipStream_t stream) {
     if (shape.total_tiles == 0) return hipSuccess;
-    launch_mfma_variant<true>(taps, x, nullptr, y, bank, shape, vec2, false, stream);
+    launch_mfma_variant<true>(taps, x, nullptr, y, bank, shape, vec2, tiled, stream);
     return hipGetLastError();
+}
+
+int fir_mfma_window_steps(int ntaps) {
+    using G = M4Geo<kMatrixOB>;
+    const int total = (ntaps + 2) / 4 + 1;
+    const int nstages = (total + G::kStageSteps - 1) / G::kStageSteps;
+    return (total + nstages - 1) / nstages;
 }
 
 int fir_bank_stride() { return kBankStride; }
