@@ -49,7 +49,7 @@ hipError_t launch_fir_f64(const double* taps, const double* x, const double* his
 // for the workgroup-tiled one (same results bit for bit).
 hipError_t launch_fir_mfma_f64(const double* taps, const double* x, const double* hist, double* y,
                                const FirShape& shape, bool vec2, bool tiled, hipStream_t stream);
-// Bank mode on the matrix pipe: the wave-autonomous kernel (510-output chunks of a row; aligned or not) unless `tiled`
+// Bank mode on the matrix pipe: the wave-autonomous kernel (1022-output chunks of a row; aligned or not) unless `tiled`
 // asks for the workgroup-tiled one (2046-output tiles).  The two chunkings group a row's taps differently, so their
 // results differ in rounding; a row's bits depend on neither the other rows nor the alignment of the buffers.
 hipError_t launch_fir_mfma_bank_f64(const double* taps, const BankRow* bank, const double* x, double* y,

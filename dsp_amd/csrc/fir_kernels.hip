@@ -1133,45 +1133,50 @@ __global__ __launch_bounds__(kBlock, RESIDENT) void fir_f64_mfma4w_kernel(const 
 
 // ---------------------------------------------------------------------------------------------
 // The wave-autonomous form for filters that need several windows (more than 569 taps; lfilter mode, 16-byte aligned
-// buffers).  As in fir_f64_mfma4w_kernel every wave is a pipeline of its own -- an LDS image and, here, a tap window
-// of its own, 512-output chunks, no workgroup barrier -- but a chunk's sums are built from several windows: window w
-// multiplies the tap offsets [4*e0, 4*(e0 + steps)) with the samples that lie 4*e0 further back, so every window
-// brings its own image and its own 292 tap slots.  There is no halo to carry; a sample is read by every window that
-// slides over it, (ntaps + 512) / 284 windows per chunk, and what keeps those reads out of HBM is the order in which
-// the chunks are taken: the waves of an XCD work on adjacent chunks at the same time, so all but the first read of a
-// sample are hits in that XCD's L2 (measured at 4095 taps over one stream: HBM reads 1.05 x the algorithmic 8 bytes
-// per output; 12.8 x when every wave walked a run of consecutive chunks of its own).  While the products of one
-// window run, the samples and taps of the next -- the next chunk's first window after a chunk's last -- are in flight
-// into registers; between two windows lies one LDS round trip.  Same products in the same order as
-// fir_f64_mfma4_kernel: same bits.
+// buffers) and for wavelet banks.  As in fir_f64_mfma4w_kernel every wave is a pipeline of its own -- an LDS image
+// and, here, a tap window of its own, no workgroup barrier -- but a chunk's sums are built from several windows:
+// window w multiplies the tap offsets [4*e0, 4*(e0 + steps)) with the samples that lie 4*e0 further back, so every
+// window brings its own image and its own tap slots.  What runs is <HG 9, OB 4>: chunks of 1024 values, 576 halo
+// slots, windows of up to 143 steps (572 tap offsets), 17.8 KB of LDS per wave, two workgroups per CU (chunks of 512
+// with windows of 71 steps, four workgroups per CU, measured 1-2 % slower from 570 to 4095 taps).  There is no halo
+// to carry; a sample is read by every window that slides over it, and what keeps those reads out of HBM is the
+// order in which the chunks are taken: the waves of an XCD work on adjacent chunks at the same time, so all but the
+// first read of a sample are hits in that XCD's L2 (at 4095 taps over one stream the HBM reads stay within a few per
+// cent of the algorithmic 8 bytes per output; 12.8 x of them when every wave walked a run of consecutive chunks of
+// its own).  While the products of one window run, the samples and taps of the next -- the next chunk's first
+// window after a chunk's last -- are in flight into registers; between two windows lies one LDS round trip.  Same
+// products in the same order as fir_f64_mfma4_kernel: same bits.
 //
 // BANK (the wavelet path, reference dsp.hpp:1136-1217): one input, rows of taps of different lengths.  A unit of work is
-// a chunk of one row: 512 values of c[t] = sum_k taps_r[k] * x[t + advance_r - k] (zeros outside [0, n)), of which the
-// first 510 leave as (c[i+1] - c[i]) * scale_r -- the first difference, the scaling and the crop fused into the
-// read-back, as in the workgroup-tiled kernel; a chunk advances by 510 outputs so that the c[i+1] (c[i+2] when the
+// a chunk of one row: 1024 values of c[t] = sum_k taps_r[k] * x[t + advance_r - k] (zeros outside [0, n)), of which the
+// first 1022 leave as (c[i+1] - c[i]) * scale_r -- the first difference, the scaling and the crop fused into the
+// read-back, as in the workgroup-tiled kernel; a chunk advances by 1022 outputs so that the c[i+1] (c[i+2] when the
 // row's advance is odd and was rounded down to keep the windows 16-byte aligned) of its last output is its own.  Rows
 // come longest first; the waves of the chip work through them together, row after row, so they all meet chunks of
 // the same cost at the same time.  VEC2 = false reads the windows with 8-byte loads (a signal that is only 8-byte
 // aligned); everything else is the same, so a row's bits do not depend on the alignment of the buffers.
-template <int RESIDENT, int OB, bool BANK, bool VEC2>
+template <int RESIDENT, int HG, int OB, bool BANK, bool VEC2>
 __global__ __launch_bounds__(kBlock, RESIDENT) void fir_f64_mfma4wm_kernel(const double* __restrict__ taps,
                                                                             const double* __restrict__ x,
                                                                             const double* __restrict__ hist,
                                                                             double* __restrict__ y,
                                                                             const BankRow* __restrict__ bank, FirShape s,
                                                                             FirRuns rn) {
-    using G = M4Geo<OB>;                                         // OB = 2: 512-output chunks, 288 halo slots; 4: 1024, 320
+    using G = M4Geo<OB>;                                         // <HG 9, OB 2>: 512-output chunks, 288 halo slots; <9, 4>: 1024, 576
     constexpr int RB = 4 * OB;
+    constexpr int kHalo = HG * G::kSeg;                          // image slots in front of the chunk
+    constexpr int kStageSteps = kHalo / 4 - 1;                   // steps of four tap offsets one window serves (71 / 143)
+    constexpr int kTapSlots = 4 * kStageSteps + 8;               // 292 / 580
     constexpr int kChunk = G::kWaveOut;                          // values per chunk: 512 / 1024
     constexpr int kOutputs = BANK ? kChunk - 2 : kChunk;         // outputs a chunk stores (and advances by)
-    constexpr int kHaloGroups = G::kHalo / G::kSeg;              // 9 / 5
-    constexpr int kImgGroups = (G::kHalo + kChunk) / G::kSeg;    // 25 / 21
+    constexpr int kHaloGroups = HG;
+    constexpr int kImgGroups = (kHalo + kChunk) / G::kSeg;    // 25 / 25
     constexpr int kGroupPairs = G::kPadStep / 2;                 // 17 / 33
     constexpr int kPG = G::kShift - 1;                           // log2 of the sample pairs per group
-    constexpr int kImgPairs = kImgGroups * kGroupPairs;          // 425 / 693
-    constexpr int kTapPairs = (G::kTapSlots + 3) / 4 * 2;        // pairs that hold the 292 / 324 tap slots of a window
-    constexpr int kWinIters = ((G::kHalo + kChunk) / 2 + 63) / 64;   // 16-byte loads per lane and window (7 / 11)
-    constexpr int kTapLoads = (G::kTapSlots + 63) / 64;              // 8-byte loads per lane and window (5 / 6)
+    constexpr int kImgPairs = kImgGroups * kGroupPairs;          // 425 / 825
+    constexpr int kTapPairs = (kTapSlots + 3) / 4 * 2;        // pairs that hold the tap slots of a window
+    constexpr int kWinIters = ((kHalo + kChunk) / 2 + 63) / 64;   // 16-byte loads per lane and window (7 / 13)
+    constexpr int kTapLoads = (kTapSlots + 63) / 64;              // 8-byte loads per lane and window (5 / 10)
     constexpr int kStores = kChunk / 64;
     constexpr int kPairStep = 64 + 128 / G::kSeg;                // image distance of pairs 64 apart
     constexpr int kBackStep = 64 + 64 / G::kSeg;
@@ -1203,7 +1208,7 @@ __global__ __launch_bounds__(kBlock, RESIDENT) void fir_f64_mfma4wm_kernel(const
     cur.tc = taps, cur.post = 1.0, cur.ntaps = s.ntaps, cur.odd = 0;
     cur.total_steps = (s.ntaps + 2) / 4 + 1;
     {
-        const int nstages = (cur.total_steps + G::kStageSteps - 1) / G::kStageSteps;
+        const int nstages = (cur.total_steps + kStageSteps - 1) / kStageSteps;
         cur.per_stage = (cur.total_steps + nstages - 1) / nstages;
     }
     Filter nxt = cur;  // (lfilter mode: one filter per launch, never written again)
@@ -1238,13 +1243,13 @@ __global__ __launch_bounds__(kBlock, RESIDENT) void fir_f64_mfma4wm_kernel(const
     // the window's steps read), tap slot i <- tap 4*e0 - 3 + i (zero outside the filter).  A window that reaches
     // outside the channel, or a tap window that reaches outside the filter, is not fetched ahead: commit() fills it
     // with range checks.
-    constexpr int kWinPairs = (G::kHalo + kChunk) / 2;   // 400 = 6 * 64 + 16 (672 = 10 * 64 + 32)
+    constexpr int kWinPairs = (kHalo + kChunk) / 2;   // 400 = 6 * 64 + 16 (800 = 12 * 64 + 32)
     dvec2 R[kWinIters];
     double T[kTapLoads];
     bool f_interior = false, f_taps_inside = false;
     auto fetch = [&](const Filter& f, const double* xc, long long pos, int e0) __attribute__((always_inline)) {
-        const long long g_lo = pos - 4 * e0 - G::kHalo;
-        f_interior = !negative(g_lo) && !negative(n - (g_lo + G::kHalo + kChunk));
+        const long long g_lo = pos - 4 * e0 - kHalo;
+        f_interior = !negative(g_lo) && !negative(n - (g_lo + kHalo + kChunk));
         if (f_interior) {
 #pragma unroll
             for (int i = 0; i < kWinIters; ++i) {
@@ -1259,11 +1264,11 @@ __global__ __launch_bounds__(kBlock, RESIDENT) void fir_f64_mfma4wm_kernel(const
             }
         }
         const int j0 = 4 * e0 - 3;
-        f_taps_inside = j0 >= 0 && j0 + G::kTapSlots <= f.ntaps;
+        f_taps_inside = j0 >= 0 && j0 + kTapSlots <= f.ntaps;
         if (f_taps_inside) {
 #pragma unroll
             for (int r = 0; r < kTapLoads; ++r)
-                if (r < kTapLoads - 1 || lane < G::kTapSlots - 64 * (kTapLoads - 1)) T[r] = scalar_base(f.tc + j0 + 64 * r)[(unsigned)lane];
+                if (r < kTapLoads - 1 || lane < kTapSlots - 64 * (kTapLoads - 1)) T[r] = scalar_base(f.tc + j0 + 64 * r)[(unsigned)lane];
         } else {  // the filter's first and last windows: the nearest tap is fetched, commit() puts zeros where none exists
             const int fl = fresh(lane) & 63;
 #pragma unroll
@@ -1276,7 +1281,7 @@ __global__ __launch_bounds__(kBlock, RESIDENT) void fir_f64_mfma4wm_kernel(const
             for (int i = 0; i < kWinIters; ++i)
                 if (i < kWinIters - 1 || lane < kWinPairs - 64 * (kWinIters - 1)) c_home[i * kPairStep] = R[i];
         } else {
-            const long long g_lo = pos - 4 * e0 - G::kHalo;
+            const long long g_lo = pos - 4 * e0 - kHalo;
 #pragma unroll 1
             for (int p = fresh(lane) & 63; p < kWinPairs; p += 64)
                 imgw[p + (p >> kPG)] = dvec2{sample_at(xc, hc, g_lo + 2 * p, n, f.ntaps), sample_at(xc, hc, g_lo + 2 * p + 1, n, f.ntaps)};
@@ -1284,13 +1289,13 @@ __global__ __launch_bounds__(kBlock, RESIDENT) void fir_f64_mfma4wm_kernel(const
         if (f_taps_inside) {
 #pragma unroll
             for (int r = 0; r < kTapLoads; ++r)
-                if (r < kTapLoads - 1 || lane < G::kTapSlots - 64 * (kTapLoads - 1)) tapw[lane + 64 * r] = T[r];
+                if (r < kTapLoads - 1 || lane < kTapSlots - 64 * (kTapLoads - 1)) tapw[lane + 64 * r] = T[r];
         } else {
             const int fl = fresh(lane) & 63;
 #pragma unroll
             for (int r = 0; r < kTapLoads; ++r) {
                 const int i = fl + 64 * r, j = 4 * e0 - 3 + i;
-                if (i < G::kTapSlots) tapw[i] = (unsigned)j < (unsigned)f.ntaps ? T[r] : 0.0;
+                if (i < kTapSlots) tapw[i] = (unsigned)j < (unsigned)f.ntaps ? T[r] : 0.0;
             }
         }
         wave_fence();
@@ -1612,6 +1617,9 @@ static bool plan_runs(unsigned nchan, long long n, unsigned max_waves, FirRuns& 
     return true;
 }
 
+// The several-windows kernel as the wavelet bank runs it: 1024-value chunks, 576 halo slots (143 steps per window).
+constexpr int kWaveBankHG = 9, kWaveBankOB = 4;
+
 template <bool BANK>
 static void launch_mfma_variant(const double* taps, const double* x, const double* hist, double* y, const BankRow* bank,
                                 const FirShape& shape, bool vec2, bool tiled, hipStream_t stream) {
@@ -1621,19 +1629,19 @@ static void launch_mfma_variant(const double* taps, const double* x, const doubl
     const dim3 grid(8 * std::max(per_xcd, 1u)), block(kBlock);
     const bool single = !BANK && shape.ntaps > 0 && (shape.ntaps + 2) / 4 + 1 <= G::kStageSteps;  // one window per tile
     if constexpr (BANK) {
-        // The wave-autonomous form: a unit of work is a 510-output chunk of one row; the positions of the tiled form's
+        // The wave-autonomous form: a unit of work is a 1022-output chunk of one row; the positions of the tiled form's
         // walk (rows * 8 runs of tiles) give the number of rows back.
         const unsigned tile_run = (shape.tiles_per_chan + 7) / 8;
         const unsigned rows = tile_run ? shape.total_tiles / (8 * tile_run) : 0;
         constexpr unsigned kWaves = kBlock / 64;
-        const unsigned max_waves = compute_units() * 4u * kWaves;
+        const unsigned max_waves = compute_units() * 2u * kWaves;
         FirRuns rn;
-        if (!tiled && rows > 0 && plan_runs(rows, shape.n, max_waves, rn, M4Geo<2>::kWaveOut - 2, 1)) {
+        if (!tiled && rows > 0 && plan_runs(rows, shape.n, max_waves, rn, M4Geo<kWaveBankOB>::kWaveOut - 2, 1)) {
             const unsigned wgs = (std::min((rn.total_runs + kWaves - 1) / kWaves, max_waves / kWaves) + 7) / 8 * 8;
             if (vec2)
-                hipLaunchKernelGGL((fir_f64_mfma4wm_kernel<4, 2, true, true>), dim3(wgs), block, 0, stream, taps, x, hist, y, bank, shape, rn);
+                hipLaunchKernelGGL((fir_f64_mfma4wm_kernel<2, kWaveBankHG, kWaveBankOB, true, true>), dim3(wgs), block, 0, stream, taps, x, hist, y, bank, shape, rn);
             else
-                hipLaunchKernelGGL((fir_f64_mfma4wm_kernel<4, 2, true, false>), dim3(wgs), block, 0, stream, taps, x, hist, y, bank, shape, rn);
+                hipLaunchKernelGGL((fir_f64_mfma4wm_kernel<2, kWaveBankHG, kWaveBankOB, true, false>), dim3(wgs), block, 0, stream, taps, x, hist, y, bank, shape, rn);
             return;
         }
     }
@@ -1642,17 +1650,16 @@ static void launch_mfma_variant(const double* taps, const double* x, const doubl
             // The wave-autonomous forms (measured on one box, tools/tap_sweep.py): up to 189 taps 512-output chunks with
             // a 288-slot halo, four workgroups per CU; up to 569 taps 1024-output chunks (half the LDS reads per matrix
             // instruction, half the chunk hand-overs) with a 320- or 576-slot halo, two workgroups per CU; beyond that
-            // several windows per 512-output chunk (per 1024-output chunk while two of its longer windows suffice:
-            // +3 % at 570 taps, where the smaller chunk needs three; no gain for longer filters).
+            // several windows per 1024-output chunk, each with a 576-slot halo (143 steps; 512-output chunks with
+            // windows of 71 steps measured 1-2 % slower from 570 to 4095 taps).
             constexpr unsigned kWaves = kBlock / 64;
             constexpr int kBigFrom = 49;   // steps of four tap offsets from which the 1024-output chunks win (190 taps)
             const int steps = (shape.ntaps + 2) / 4 + 1;
             const bool big = steps >= kBigFrom && steps <= 2 * M4Geo<2>::kStageSteps + 1;
             const bool several = steps > 2 * M4Geo<2>::kStageSteps + 1;   // several windows per chunk: runs of one chunk
-            const bool wm4 = several && steps <= 2 * M4Geo<4>::kStageSteps;  // ... two windows of 1024-output chunks (570-629 taps)
-            const unsigned max_waves = compute_units() * ((big || wm4) ? 2u : 4u) * kWaves;
+            const unsigned max_waves = compute_units() * ((big || several) ? 2u : 4u) * kWaves;
             FirRuns rn;
-            if (plan_runs(shape.total_tiles / shape.tiles_per_chan, shape.n, max_waves, rn, (big || wm4) ? 1024 : 512, several ? 1 : 0)) {
+            if (plan_runs(shape.total_tiles / shape.tiles_per_chan, shape.n, max_waves, rn, (big || several) ? 1024 : 512, several ? 1 : 0)) {
                 unsigned wgs = std::min((rn.total_runs + kWaves - 1) / kWaves, max_waves / kWaves);
                 if (several) wgs = (wgs + 7) / 8 * 8;   // (its waves are addressed by XCD)
                 const dim3 wgrid(wgs);
@@ -1662,10 +1669,8 @@ static void launch_mfma_variant(const double* taps, const double* x, const doubl
                     hipLaunchKernelGGL((fir_f64_mfma4w_kernel<2, 5, 4>), wgrid, block, 0, stream, taps, x, hist, y, shape, rn);
                 else if (big)
                     hipLaunchKernelGGL((fir_f64_mfma4w_kernel<2, 9, 4>), wgrid, block, 0, stream, taps, x, hist, y, shape, rn);
-                else if (wm4)
-                    hipLaunchKernelGGL((fir_f64_mfma4wm_kernel<2, 4, false, true>), wgrid, block, 0, stream, taps, x, hist, y, bank, shape, rn);
                 else
-                    hipLaunchKernelGGL((fir_f64_mfma4wm_kernel<4, 2, false, true>), wgrid, block, 0, stream, taps, x, hist, y, bank, shape, rn);
+                    hipLaunchKernelGGL((fir_f64_mfma4wm_kernel<2, kWaveBankHG, kWaveBankOB, false, true>), wgrid, block, 0, stream, taps, x, hist, y, bank, shape, rn);
                 return;
             }
         }
@@ -1698,9 +1703,9 @@ hipError_t launch_fir_mfma_bank_f64(const double* taps, const BankRow* bank, con
 }
 
 int fir_mfma_window_steps(int ntaps) {
-    using G = M4Geo<kMatrixOB>;
+    constexpr int kStageSteps = kWaveBankHG * M4Geo<kWaveBankOB>::kSeg / 4 - 1;   // what a window of the bank's kernel serves
     const int total = (ntaps + 2) / 4 + 1;
-    const int nstages = (total + G::kStageSteps - 1) / G::kStageSteps;
+    const int nstages = (total + kStageSteps - 1) / kStageSteps;
     return (total + nstages - 1) / nstages;
 }
 

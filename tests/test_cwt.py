@@ -134,11 +134,11 @@ def test_seeded_cwt_vs_reference_output(dsp, oracle, golden):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n", [1, 2, 7, 100, 509, 510, 511, 512, 1019, 1020, 1021, 2039, 2040, 2041, 2045, 2046, 2047, 2048,
+@pytest.mark.parametrize("n", [1, 2, 7, 100, 1021, 1022, 1023, 1024, 2039, 2040, 2041, 2043, 2044, 2045, 2046, 2047, 2048,
                                4081, 4093, 4094, 4095, 8189, 10000])
 def test_cwt_lengths_vs_oracle(dsp, oracle, golden, n):
     """Signals shorter than the kernels, and lengths around the strides of bank mode (2040 outputs per workgroup on the
-    vector pipe; 510 per wave on the matrix pipe, 2046 and 4094 per workgroup in its tiled form)."""
+    vector pipe; 1022 per wave on the matrix pipe, 2046 and 4094 per workgroup in its tiled form)."""
     psi, wx = golden["morlet10_psi"], golden["morlet10_x"]
     sig = oracle.fill_splitmix(n, dsp.SEED, n)
     scales = [0.7, 1.0, 3.3, 16.0, 65.0]
