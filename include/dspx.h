@@ -48,9 +48,10 @@ typedef enum dspx_status {
 #define DSPX_FIR_MFMA 2u   /* force the matrix pipe (ignored together with DSPX_FIR_EXACT)                   */
 #define DSPX_FIR_VECTOR 4u /* force the vector pipe                                                          */
 #define DSPX_FIR_TILED 8u  /* matrix pipe only: run the workgroup-tiled form of the kernel also where the
-                              wave-autonomous forms (16-byte aligned buffers, any tap count) are the default.
-                              Same results bit for bit; kept so that the forms can be measured against each
-                              other                                                                          */
+                              wave-autonomous forms are the default (filters over 16-byte aligned buffers at any
+                              tap count; wavelet banks).  Filters: same results bit for bit.  Wavelet banks: the
+                              forms cut a row into different chunks, so their results differ in rounding.  Kept
+                              so that the forms can be measured against each other                           */
 
 DSPX_API int dspx_version(void);
 /* Number of visible HIP devices (0 if none or the runtime is unusable). */
