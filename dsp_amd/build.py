@@ -18,7 +18,11 @@ SOURCES = ["fir_kernels.hip", "iir_kernels.hip", "dspx_capi.hip", "dspx_cwt.hip"
 HEADERS = [os.path.join(CSRC, "fir_kernels.h"), os.path.join(CSRC, "iir_kernels.h"), os.path.join(CSRC, "dspx_common.h"), os.path.join(ROOT, "include", "dspx.h"),
            os.path.join(ROOT, "include", "dsp.hpp")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++20", "-ffp-contract=off", "-fPIC", "-shared",
-         "-fvisibility=hidden", "-mllvm", "-amdgpu-mfma-vgpr-form", "-Wall", "-Wextra", "-Wno-unused-parameter"]
+         "-fvisibility=hidden", "-mllvm", "-amdgpu-mfma-vgpr-form",
+         # the FIR kernels draw their next run with an atomic whose result is read a whole run later: the pass that
+         # combines a wave's atomics would read it (and wait for it) at once
+         "-mllvm", "-amdgpu-atomic-optimizer-strategy=None",
+         "-Wall", "-Wextra", "-Wno-unused-parameter"]
 
 
 def hipcc() -> str:

@@ -268,7 +268,7 @@ void destroy_engine(Engine* e) {
     (void)hipGetDevice(&cur);
     (void)hipSetDevice(e->device);
     for (auto& s : e->slots) {
-        if (s.stream) (void)hipStreamSynchronize(s.stream), (void)hipStreamDestroy(s.stream);
+        if (s.stream) (void)hipStreamSynchronize(s.stream), dspx::forget_stream(s.stream), (void)hipStreamDestroy(s.stream);
         if (s.done) (void)hipEventDestroy(s.done);
         if (s.pin_in) (void)hipHostFree(s.pin_in);
         if (s.pin_out) (void)hipHostFree(s.pin_out);

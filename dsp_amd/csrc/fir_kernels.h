@@ -55,6 +55,10 @@ hipError_t launch_fir_mfma_f64(const double* taps, const double* x, const double
 hipError_t launch_fir_mfma_bank_f64(const double* taps, const BankRow* bank, const double* x, double* y,
                                     const FirShape& shape, bool vec2, bool tiled, hipStream_t stream);
 int fir_mfma_window_steps(int ntaps);  // for BankRow::win_steps
+// The matrix-pipe kernels keep a small set of device counters per stream they have been launched on (launches of one
+// stream hand their work out through them).  A caller that destroys a stream tells the launcher first, with the
+// stream idle and its device current, so that the set can serve another stream.
+void forget_stream(hipStream_t stream);
 // Bank mode: shape.n = length of the single input and of every output row, shape.y_stride = elements
 // between output rows, shape.tiles_per_chan = ceil(n / fir_bank_stride()), shape.total_tiles =
 // rows * 8 * ceil(tiles_per_chan / 8) workgroups (each row is cut into 8 runs of tiles, one per XCD; the

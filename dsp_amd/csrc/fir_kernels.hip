@@ -26,7 +26,9 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
+#include <mutex>
 #include <type_traits>
 
 #include "fir_kernels.h"
@@ -810,14 +812,56 @@ __global__ __launch_bounds__(kBlock, OB == 4 ? 2 : 4) void fir_f64_mfma4_kernel(
 // state, to time the kernel without that memory traffic.  The results of such a build are wrong.
 #define M4W_ABLATE 0
 #endif
+constexpr unsigned kMaxRunDecks = 8, kTicketStride = 64;   // (64 unsigned = 256 bytes between the counters of two groups)
 struct FirRuns {
     unsigned long long div_magic;  // run / runs_per_chan == (run * div_magic) >> div_shift
     unsigned div_shift;
-    unsigned runs_per_chan;        // a channel's chunks are cut into this many runs ...
+    unsigned runs_per_chan;        // a channel's chunks [0, lead_chunks) are cut into this many runs ...
     unsigned run_chunks;           // ... of this many chunks (the last one may be shorter)
     unsigned chunks_per_chan;      // ceil(n / outputs per chunk)
-    unsigned total_runs;           // nchan * runs_per_chan
+    unsigned total_runs;           // lead_runs + nchan * tail_runs_per_chan
+    // Runs handed out in order by a counter (tickets != nullptr; otherwise wave w takes runs w, w + waves, ...).  The
+    // waves of a SIMD are served oldest first and progress at different speeds, so equal shares leave the youngest
+    // waves working alone at the end of a launch.  With a counter every wave draws its next run while it works on the
+    // current one; the runs that are drawn last -- the tail part of every channel -- are short, so that the waves end
+    // within a few chunks of each other.
+    // The workgroups of a launch form `decks` groups (1, 2, 4 or 8) by blockIdx.x % decks; group g is dealt the runs g,
+    // g + decks, ... from a counter of its own (kTicketStride apart).  One counter serves some 40 draws per
+    // microsecond: a launch of several milliseconds stays far below that with a single counter -- and the eight XCDs,
+    // which do not run equally fast, then share the work as they go --, a launch of one millisecond with its few dozen
+    // draws per wave needs eight.
+    unsigned* tickets;             // per group: [0] the group's next draw minus its waves, [1] its workgroups that have ended
+    unsigned decks;
+    unsigned lead_runs;            // nchan * runs_per_chan: runs [0, lead_runs) are the long ones
+    unsigned lead_chunks;          // chunks of a channel that the long runs cover (chunks_per_chan without a tail part)
+    unsigned tail_chan0, tail_c0;  // the short runs start at this channel and, within a channel, at this chunk
+    unsigned tail_runs_per_chan;   // a channel's chunks [tail_c0, chunks_per_chan) are cut into this many runs ...
+    unsigned tail_run_chunks;      // ... of this many chunks
+    unsigned tail_div_shift;
+    unsigned long long tail_div_magic;
 };
+
+// Run number -> the chunks [c0, c1) of channel `chan` it covers.
+struct RunSpan {
+    unsigned chan, c0, c1;
+};
+__host__ __device__ __forceinline__ RunSpan run_span(const FirRuns& rn, unsigned run) {
+    RunSpan r;
+    if (run < rn.lead_runs) {
+        r.chan = (unsigned)(((unsigned long long)run * rn.div_magic) >> rn.div_shift);
+        r.c0 = (run - r.chan * rn.runs_per_chan) * rn.run_chunks;
+        const unsigned end = r.c0 + rn.run_chunks;
+        r.c1 = end < rn.lead_chunks ? end : rn.lead_chunks;
+    } else {
+        const unsigned u = run - rn.lead_runs;
+        const unsigned tc = (unsigned)(((unsigned long long)u * rn.tail_div_magic) >> rn.tail_div_shift);
+        r.chan = rn.tail_chan0 + tc;
+        r.c0 = rn.tail_c0 + (u - tc * rn.tail_runs_per_chan) * rn.tail_run_chunks;
+        const unsigned end = r.c0 + rn.tail_run_chunks;
+        r.c1 = end < rn.chunks_per_chan ? end : rn.chunks_per_chan;
+    }
+    return r;
+}
 
 __device__ __forceinline__ void wave_fence() {
     // Orders this wave's LDS accesses as written (other lanes of the wave read what this lane wrote); the hardware
@@ -868,6 +912,7 @@ __global__ __launch_bounds__(kBlock, RESIDENT) void fir_f64_mfma4w_kernel(const 
     static_assert(kChunk / G::kSeg * G::kOutStep <= (kImgGroups - kHaloGroups) * G::kPadStep,
                   "the transposed results fit in the body's place");
     __shared__ double2 lds[kTapDoubles / 2 + (kBlock / 64) * kImgPairs];
+    __shared__ unsigned waves_ended;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -888,6 +933,7 @@ __global__ __launch_bounds__(kBlock, RESIDENT) void fir_f64_mfma4w_kernel(const 
         const int i = tid + r * kBlock, j = i - 3;
         if (i < kTapSlots) tapz[i] = (j >= 0 && j < ntaps) ? taps[j] : 0.0;
     }
+    if (tid == 0) waves_ended = 0;
     __syncthreads();
 
     const int steps = (ntaps + 2) / 4 + 1;                                        // <= kStageSteps (the launcher picks HG so)
@@ -932,19 +978,28 @@ __global__ __launch_bounds__(kBlock, RESIDENT) void fir_f64_mfma4w_kernel(const 
     const unsigned long long t_begin = stamp();
     const unsigned long long r_begin = __builtin_amdgcn_s_memrealtime();
 #endif
-    for (unsigned run = blockIdx.x * (kBlock / 64) + wave; run < rn.total_runs; run += nwaves) {
-        const unsigned chan = (unsigned)(((unsigned long long)run * rn.div_magic) >> rn.div_shift);
-        const unsigned c0 = (run - chan * rn.runs_per_chan) * rn.run_chunks;
-        const unsigned c1 = min(c0 + rn.run_chunks, rn.chunks_per_chan);
+    // Drawn runs: this workgroup's group, its counters, its waves, and this wave's place among them.
+    const unsigned decks = rn.decks;                       // (a power of two that divides the grid)
+    const unsigned deck = blockIdx.x & (decks - 1);
+    unsigned* const tickets = rn.tickets != nullptr ? rn.tickets + deck * kTicketStride : nullptr;
+    const unsigned deck_blocks = gridDim.x / decks;
+    const unsigned deck_waves = deck_blocks * (kBlock / 64);
+    const int npairs = (kHalo + kChunk - qlo) / 2;   // sample pairs of a run's first window
+    static_assert(kBodyIters + kHaloIters >= kFirstIters, "a first window fits in the registers of a body and a halo");
+    bool window_ready = false;   // the image holds the run's first window already (fetched during the run before)
+    for (unsigned run = tickets != nullptr ? decks * ((blockIdx.x / decks) * (kBlock / 64) + wave) + deck
+                                           : blockIdx.x * (kBlock / 64) + wave;
+         run < rn.total_runs;) {
+        const RunSpan span = run_span(rn, run);
+        const unsigned chan = span.chan, c0 = span.c0, c1 = span.c1;
         const double* __restrict__ xc = x + (unsigned long long)chan * s.x_stride;
         const double* __restrict__ hc = hist ? hist + (unsigned long long)chan * s.hist_stride : nullptr;
         double* __restrict__ yc = y + (unsigned long long)chan * s.y_stride;
 
         // ---- the run's first window: image slot q <- sample 512*c0 - kHalo + q for q >= qlo ----
-        {
+        if (!window_ready) {
             const long long start = (long long)c0 * kChunk;
             const long long g_lo = start - kHalo + qlo;
-            const int npairs = (kHalo + kChunk - qlo) / 2;
             if (!negative(g_lo) && !negative(n - (start + kChunk))) {
                 const dvec2* src = reinterpret_cast<const dvec2*>(xc + g_lo);
                 dvec2 F[kFirstIters];
@@ -962,18 +1017,47 @@ __global__ __launch_bounds__(kBlock, RESIDENT) void fir_f64_mfma4w_kernel(const 
             }
             wave_fence();
         }
+        // The next run is drawn now (the first window's loads have arrived, so nothing waits for this one): its number
+        // is back long before this run's last chunk, which fetches that run's first window.
+        unsigned drawn = 0;
+        if (tickets != nullptr && lane == 0)
+            drawn = __hip_atomic_fetch_add(tickets, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned next_run = rn.total_runs;
+        window_ready = false;
 
         const double* xn = xc + (unsigned long long)(c0 + 1) * kChunk;  // the body of the chunk after the current one
         double* yk = yc + (unsigned long long)c0 * kChunk;
         long long left = n - (long long)c0 * kChunk;                    // outputs of the channel from this chunk on
-        for (unsigned k = c0; k < c1; ++k, xn += kChunk, yk += kChunk, left -= kChunk) {
-            const bool have_next = k + 1 < c1;
+        // One chunk of the run.  `last` (compile time): the run's last chunk, whose hand-over installs not the next
+        // chunk's body and halo but the whole first window of the wave's next run, fetched while the products run --
+        // a change of run then costs what a change of chunk costs.  (Two copies of the code, so that the registers of
+        // the two cases never meet.)
+        auto do_chunk = [&](auto last, const unsigned k) __attribute__((always_inline)) {
+            constexpr bool have_next = !decltype(last)::value;
             const bool next_full = have_next && !negative(left - 2 * kChunk) && !(M4W_ABLATE & 16);  // the next body lies inside the channel
-            dvec2 R[kBodyIters];
-            if (next_full) {
+            dvec2 R[have_next ? kBodyIters : 1];
+            dvec2 F[have_next ? 1 : kFirstIters];
+            bool switch_run = false;
+            if constexpr (have_next) {
+                if (next_full) {
 #pragma unroll
-                for (int i = 0; i < kBodyIters; ++i)
-                    R[i] = stream_load(scalar_base(reinterpret_cast<const dvec2*>(xn) + 64 * i) + (unsigned)lane);
+                    for (int i = 0; i < kBodyIters; ++i)
+                        R[i] = stream_load(scalar_base(reinterpret_cast<const dvec2*>(xn) + 64 * i) + (unsigned)lane);
+                }
+            } else {
+                next_run = tickets != nullptr ? decks * (deck_waves + (unsigned)__builtin_amdgcn_readfirstlane((int)drawn)) + deck
+                                              : run + nwaves;
+                if (next_run < rn.total_runs) {
+                    const RunSpan ns = run_span(rn, next_run);
+                    const long long nstart = (long long)ns.c0 * kChunk, ng_lo = nstart - kHalo + qlo;
+                    if (!negative(ng_lo) && !negative(n - (nstart + kChunk))) {   // (else: range-checked, at the top of that run)
+                        switch_run = true;
+                        const dvec2* src = reinterpret_cast<const dvec2*>(x + (unsigned long long)ns.chan * s.x_stride + ng_lo);
+#pragma unroll
+                        for (int i = 0; i < kFirstIters; ++i)
+                            if (lane + 64 * i < npairs) F[i] = scalar_base(src + 64 * i)[(unsigned)lane];
+                    }
+                }
             }
             // The first sample vectors and the image's tail (the next chunk's halo) are asked for before the finished
             // chunk's stores wait for its values: everything below up to the first matrix instruction is then one
@@ -985,8 +1069,8 @@ __global__ __launch_bounds__(kBlock, RESIDENT) void fir_f64_mfma4w_kernel(const 
             const double* wp = w_home - G::kPadStep;
             const double* ap = a_home;
             double a_now = ap[0];
-            dvec2 Tl[kHaloIters];
-            if (have_next) {
+            dvec2 Tl[have_next ? kHaloIters : 1];
+            if constexpr (have_next) {
 #pragma unroll
                 for (int i = 0; i < kHaloIters; ++i)
                     if (lane + 64 * i < hpairs) Tl[i] = t_src[64 * i];
@@ -1069,7 +1153,7 @@ __global__ __launch_bounds__(kBlock, RESIDENT) void fir_f64_mfma4w_kernel(const 
             // The whole image is dead now (its tail is in Tl): the halo of the next chunk goes to its place, the
             // results pass through the body's place, and the next body follows them there.  A wave's LDS instructions
             // execute in order, so none of these waits for another.
-            if (have_next) {
+            if constexpr (have_next) {
 #pragma unroll
                 for (int i = 0; i < kHaloIters; ++i)
                     if (lane + 64 * i < hpairs) t_dst[64 * i] = Tl[i];
@@ -1096,7 +1180,7 @@ __global__ __launch_bounds__(kBlock, RESIDENT) void fir_f64_mfma4w_kernel(const 
 #pragma unroll
             for (int j = 0; j < kStores; ++j) O[j] = g_home[j * kBackStep];
             wave_fence();
-            if (have_next) {
+            if constexpr (have_next) {
                 if (next_full) {
 #pragma unroll
                     for (int i = 0; i < kBodyIters; ++i) b_dst[i * kPairStep] = R[i];
@@ -1107,14 +1191,33 @@ __global__ __launch_bounds__(kBlock, RESIDENT) void fir_f64_mfma4w_kernel(const 
                         imgw[kHaloGroups * kGroupPairs + p + (p >> kPG)] =
                             dvec2{sample_at(xc, hc, pos + 2 * p, n, ntaps), sample_at(xc, hc, pos + 2 * p + 1, n, ntaps)};
                 }
+            } else if (switch_run) {
+#pragma unroll
+                for (int i = 0; i < kFirstIters; ++i)
+                    if (lane + 64 * i < npairs) f_dst[i * kPairStep] = F[i];
+                window_ready = true;
             }
             wave_fence();
             pend_yt = yk;
             pend_left = negative(left - kChunk) ? (int)left : kChunk;
             stores_due = true;
-        }
+        };
+        unsigned k = c0;
+        for (; k + 1 < c1; ++k, xn += kChunk, yk += kChunk, left -= kChunk) do_chunk(std::false_type{}, k);
+        do_chunk(std::true_type{}, k);
+        run = next_run;
     }
     if (stores_due) store_chunk();
+    if (tickets != nullptr && lane == 0) {
+        // The last workgroup of the group to end leaves its counters at zero for the next launch on this stream.
+        // (Every wave has drawn its last, out-of-range number before it counts itself here; a workgroup's waves count
+        // themselves in LDS, so that the counter in memory sees one addition per workgroup.)
+        if (__hip_atomic_fetch_add(&waves_ended, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == kBlock / 64 - 1 &&
+            __hip_atomic_fetch_add(tickets + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == deck_blocks - 1) {
+            __hip_atomic_store(tickets, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(tickets + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 #ifdef DSPX_M4W_TIMING
     {
         const unsigned long long t_end = stamp();
@@ -1591,30 +1694,126 @@ static unsigned compute_units() {
     return cached[dev] = (unsigned)cus;
 }
 
+static std::atomic<int> g_share_mode{0};   // test hook (dspx_test_run_shares): 1 fixed shares, 2 drawn runs for any input size
+
 // Cuts `nchan` channels of `n` samples into runs of consecutive chunks of `kChunk` outputs for the wave-autonomous kernels: a
 // run never crosses a channel; with a large input there are about kRunsPerWave runs per resident wave, so that the
 // waves end together, and never fewer than kMinRun chunks per run unless the input is too small to occupy every
 // wave that way (a run's first window is fetched with its halo, the only samples read twice).
+//
+// With `tickets` (a counter pair of the launch's stream) and an input of kDrawnFrom chunks per wave or more, the runs
+// are handed out in order instead (see FirRuns): long runs over the first three quarters of the input -- of every
+// channel when there are few channels, the first three quarters of the channels otherwise --, about kLeadPerWave per
+// wave, then runs an eighth as long over the rest.
 static bool plan_runs(unsigned nchan, long long n, unsigned max_waves, FirRuns& rn, unsigned long long kChunk,
-                      unsigned long long fixed_run = 0) {
-    constexpr unsigned long long kRunsPerWave = 8, kMinRun = 32;
+                      unsigned long long fixed_run = 0, unsigned* tickets = nullptr) {
+    constexpr unsigned long long kRunsPerWave = 8, kMinRun = 32, kDrawnFrom = 32, kLeadPerWave = 6, kTailDiv = 8, kFewChannels = 16;
     const unsigned long long cpc = ((unsigned long long)n + kChunk - 1) / kChunk, total_chunks = cpc * nchan;
     unsigned long long want = (total_chunks + kRunsPerWave * max_waves - 1) / (kRunsPerWave * max_waves);
     if (want < kMinRun) want = std::min(kMinRun, std::max<unsigned long long>(1, total_chunks / max_waves));
     if (fixed_run) want = fixed_run;   // (a kernel that carries nothing from chunk to chunk)
-    want = std::min(want, cpc);
+    const unsigned long long per_wave = total_chunks / max_waves;
+    const bool drawn = tickets != nullptr && !fixed_run && cpc <= 0x7fffffffull &&
+                       (per_wave >= kDrawnFrom || g_share_mode.load(std::memory_order_relaxed) == 2);
+    unsigned long long lead_nchan = nchan, lead_chunks = cpc, tail_run = 0;
+    if (drawn) {
+        want = std::max(kMinRun, per_wave * 3 / 4 / kLeadPerWave);
+        tail_run = std::max<unsigned long long>(4, std::min(want, cpc) / kTailDiv);
+        if (nchan < kFewChannels) {
+            lead_chunks = cpc * 3 / 4 / std::min(want, cpc) * std::min(want, cpc);   // whole long runs
+        } else {
+            lead_nchan = (unsigned long long)nchan * 3 / 4;
+        }
+    }
+    want = std::min(want, std::max<unsigned long long>(lead_chunks, 1));
     rn = FirRuns{};
+    rn.decks = 1;
     rn.chunks_per_chan = (unsigned)cpc;
-    rn.runs_per_chan = (unsigned)((cpc + want - 1) / want);
-    rn.run_chunks = (unsigned)((cpc + rn.runs_per_chan - 1) / rn.runs_per_chan);
-    rn.runs_per_chan = (unsigned)((cpc + rn.run_chunks - 1) / rn.run_chunks);
-    const unsigned long long total_runs = (unsigned long long)nchan * rn.runs_per_chan;
-    if (cpc > 0x7fffffffull || total_runs >= (1ull << 31)) return false;  // (the divider below covers 31 bits)
-    rn.total_runs = (unsigned)total_runs;
+    rn.lead_chunks = (unsigned)lead_chunks;
+    rn.runs_per_chan = (unsigned)((lead_chunks + want - 1) / want);
+    rn.run_chunks = rn.runs_per_chan ? (unsigned)((lead_chunks + rn.runs_per_chan - 1) / rn.runs_per_chan) : 1;
+    rn.runs_per_chan = (unsigned)((lead_chunks + rn.run_chunks - 1) / rn.run_chunks);
+    const unsigned long long lead_runs = lead_nchan * rn.runs_per_chan;
+    unsigned long long tail_runs = 0;
     FirShape d{};
-    set_divider(d, rn.runs_per_chan);
+    if (drawn) {
+        rn.tail_chan0 = nchan < kFewChannels ? 0u : (unsigned)lead_nchan;
+        rn.tail_c0 = nchan < kFewChannels ? (unsigned)lead_chunks : 0u;
+        const unsigned long long tail_chunks = cpc - rn.tail_c0;
+        rn.tail_run_chunks = (unsigned)std::min(tail_run, std::max<unsigned long long>(tail_chunks, 1));
+        rn.tail_runs_per_chan = (unsigned)((tail_chunks + rn.tail_run_chunks - 1) / rn.tail_run_chunks);
+        tail_runs = (unsigned long long)(nchan - rn.tail_chan0) * rn.tail_runs_per_chan;
+        set_divider(d, std::max(rn.tail_runs_per_chan, 1u));
+        rn.tail_div_magic = d.div_magic, rn.tail_div_shift = d.div_shift;
+        rn.tickets = tickets;
+    }
+    const unsigned long long total_runs = lead_runs + tail_runs;
+    if (cpc > 0x7fffffffull || total_runs >= (1ull << 31)) return false;  // (the dividers cover 31 bits)
+    rn.lead_runs = (unsigned)lead_runs;
+    rn.total_runs = (unsigned)total_runs;
+    set_divider(d, std::max(rn.runs_per_chan, 1u));
     rn.div_magic = d.div_magic, rn.div_shift = d.div_shift;
     return true;
+}
+
+// Counters for launches whose runs are drawn (FirRuns::tickets): one set per stream, so that two launches that may
+// run at the same time never share one, while the launches of one stream, which run one after the other, each find
+// the zeros the launch before them left.  A device has kTicketSlots sets.  A stream keeps its set until
+// forget_stream() gives it back (the library does that for the streams it creates itself, before it destroys them);
+// when all sets are taken, further streams get none and their launches use fixed shares.  Launches that are being
+// captured into a graph always do: a graph may be replayed on any stream.
+constexpr int kTicketSlots = 64;
+__device__ unsigned g_run_tickets[kTicketSlots][kMaxRunDecks * kTicketStride];
+
+struct TicketTable {
+    unsigned* base = nullptr;
+    bool looked_up = false;
+    bool taken[kTicketSlots] = {};
+    hipStream_t streams[kTicketSlots] = {};
+};
+static std::mutex g_ticket_mutex;
+static TicketTable g_ticket_tables[64];   // per device
+
+static unsigned* ticket_set(hipStream_t stream) {
+    if (g_share_mode.load(std::memory_order_relaxed) == 1) return nullptr;
+    if (stream == hipStreamPerThread || stream == hipStreamLegacy) return nullptr;   // (handles that name several streams)
+    hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &capture) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    if (capture != hipStreamCaptureStatusNone) return nullptr;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> lock(g_ticket_mutex);
+    TicketTable& d = g_ticket_tables[dev];
+    if (!d.looked_up) {
+        d.looked_up = true;
+        void* p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_run_tickets)) == hipSuccess)
+            d.base = static_cast<unsigned*>(p);
+        else
+            (void)hipGetLastError();
+    }
+    if (d.base == nullptr) return nullptr;
+    int slot = -1, vacant = -1;
+    for (int i = 0; i < kTicketSlots && slot < 0; ++i) {
+        if (d.taken[i] && d.streams[i] == stream) slot = i;
+        if (!d.taken[i] && vacant < 0) vacant = i;
+    }
+    if (slot < 0) slot = vacant;
+    if (slot < 0) return nullptr;
+    d.taken[slot] = true, d.streams[slot] = stream;
+    return d.base + (size_t)slot * kMaxRunDecks * kTicketStride;
+}
+
+void forget_stream(hipStream_t stream) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return;
+    std::lock_guard<std::mutex> lock(g_ticket_mutex);
+    TicketTable& d = g_ticket_tables[dev];
+    for (int i = 0; i < kTicketSlots; ++i)
+        if (d.taken[i] && d.streams[i] == stream) d.taken[i] = false;
 }
 
 // The several-windows kernel as the wavelet bank runs it: 1024-value chunks, 576 halo slots (143 steps per window).
@@ -1659,9 +1858,19 @@ static void launch_mfma_variant(const double* taps, const double* x, const doubl
             const bool several = steps > 2 * M4Geo<2>::kStageSteps + 1;   // several windows per chunk: runs of one chunk
             const unsigned max_waves = compute_units() * ((big || several) ? 2u : 4u) * kWaves;
             FirRuns rn;
-            if (plan_runs(shape.total_tiles / shape.tiles_per_chan, shape.n, max_waves, rn, (big || several) ? 1024 : 512, several ? 1 : 0)) {
+            if (plan_runs(shape.total_tiles / shape.tiles_per_chan, shape.n, max_waves, rn, (big || several) ? 1024 : 512, several ? 1 : 0,
+                          several ? nullptr : ticket_set(stream))) {
                 unsigned wgs = std::min((rn.total_runs + kWaves - 1) / kWaves, max_waves / kWaves);
                 if (several) wgs = (wgs + 7) / 8 * 8;   // (its waves are addressed by XCD)
+                if (rn.tickets != nullptr) {
+                    wgs = std::max(wgs / kMaxRunDecks * kMaxRunDecks, kMaxRunDecks);   // (groups of equal size)
+                    // how long the launch will take, roughly (60 TFLOP/s, 5 TB/s), and the draws per microsecond that makes
+                    const double outputs = (double)shape.n * (shape.total_tiles / shape.tiles_per_chan);
+                    const double micros = std::max(outputs * 2.0 * shape.ntaps / 60e6, outputs * 16.0 / 5e6);
+                    constexpr double kDrawsPerMicro = 10.0;   // per counter
+                    rn.decks = 1;
+                    while (rn.decks < kMaxRunDecks && rn.total_runs > kDrawsPerMicro * micros * rn.decks) rn.decks *= 2;
+                }
                 const dim3 wgrid(wgs);
                 if (steps < kBigFrom)
                     hipLaunchKernelGGL((fir_f64_mfma4w_kernel<4, 9, 2>), wgrid, block, 0, stream, taps, x, hist, y, shape, rn);
@@ -1792,6 +2001,34 @@ hipError_t launch_checksum(const double* yv, unsigned long long n, unsigned long
 }
 
 }  // namespace dspx
+
+// Test hooks (not part of the C ABI, include/dspx.h does not declare them; results do not depend on them).
+// dspx_test_run_shares: 1 makes every launch of the wave-autonomous kernels use fixed shares of runs per wave, as
+// launches under stream capture do; 2 makes them draw their runs from the stream's counter whatever the input's
+// size (by default only inputs of 32 chunks per wave or more do); 0 restores the default.  Returns the previous
+// setting.  dspx_test_forget_stream: gives an idle stream's counters back (what the library does for its own
+// streams before it destroys them).  dspx_test_run_plan: the runs plan_runs() cuts an input into, decoded as the kernels decode them
+// (chan, first chunk, end chunk per run); returns the number of runs, or -1 when the plan does not fit `cap`.
+extern "C" __attribute__((visibility("default"))) int dspx_test_run_shares(int mode) {
+    return dspx::g_share_mode.exchange(mode);
+}
+extern "C" __attribute__((visibility("default"))) void dspx_test_forget_stream(void* stream) {
+    dspx::forget_stream(static_cast<hipStream_t>(stream));
+}
+extern "C" __attribute__((visibility("default"))) long long dspx_test_run_plan(unsigned nchan, long long n, unsigned max_waves,
+                                                                            unsigned chunk, int drawn, unsigned* spans,
+                                                                            size_t cap, unsigned* lead_runs) {
+    dspx::FirRuns rn;
+    unsigned dummy[1];
+    if (!dspx::plan_runs(nchan, n, max_waves, rn, chunk, 0, drawn ? dummy : nullptr)) return -1;
+    if (rn.total_runs > cap) return -1;
+    for (unsigned r = 0; r < rn.total_runs; ++r) {
+        const dspx::RunSpan sp = dspx::run_span(rn, r);
+        spans[3 * r] = sp.chan, spans[3 * r + 1] = sp.c0, spans[3 * r + 2] = sp.c1;
+    }
+    if (lead_runs) *lead_runs = rn.tickets ? rn.lead_runs : rn.total_runs;
+    return rn.total_runs;
+}
 
 #ifdef DSPX_M4W_TIMING
 extern "C" __attribute__((visibility("default"))) int dspx_debug_m4w_timing(unsigned long long* out, size_t count) {

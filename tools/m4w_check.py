@@ -12,6 +12,8 @@ import dsp_amd
 from oracle.pyoracle import Oracle
 
 orc = Oracle()
+if os.environ.get("M4W_SHARES"):   # 1: fixed shares of runs per wave, 2: runs drawn from the stream's counter at any size
+    dsp_amd.lib().dspx_test_run_shares(int(os.environ["M4W_SHARES"]))
 bad = 0
 rng = np.random.default_rng(7)
 cases = [(1, 512, 101), (1, 513, 101), (3, 5000, 255), (2, 100, 63), (1, 1 << 16, 281), (5, 70001, 57), (64, 1 << 14, 128),

@@ -12,6 +12,8 @@ import torch
 import dsp_amd
 from dsp_amd._lib import lib
 
+if os.environ.get("M4W_SHARES"):   # 1: fixed shares of runs per wave, 2: runs drawn from the stream's counter at any size
+    lib().dspx_test_run_shares(int(os.environ["M4W_SHARES"]))
 W = {"b160": (2048, 1 << 20, 160), "b96": (2048, 1 << 20, 96), "b255": (4096, 1 << 20, 255), "l101": (1, 1 << 28, 101), "b128": (2048, 1 << 20, 128), "b63": (1024, 1 << 20, 63)}
 for nm in sys.argv[1:] or ["l101"]:
     nchan, n, nt = W[nm]
@@ -64,4 +66,9 @@ for nm in sys.argv[1:] or ["l101"]:
               f"rest {np.mean(rest[m] / nch[m]):7.0f}  lifetime {np.mean((t1 - t0)[m]):9.0f}  first 64 chunks {np.mean((t64 - t0)[m & (t64 > 0)]) / 64:8.0f} per chunk")
     share = sum(steps * rb * 16 / (np.mean((t64 - t0)[(ranks == r) & (t64 > 0)]) / 64) for r in range(ranks.max() + 1))
     print(f"   matrix pipe share while all waves run (first 64 chunks): {share:.3f}")
+    # per XCD: the XCDs do not run equally fast (span = first wave start to last wave end on that XCD)
+    for g in np.unique(xc):
+        m = xc == g
+        print(f"   XCD {int(g)}: {m.sum():4d} waves  chunks per wave {nch[m].mean():7.1f}  per chunk {np.mean((t1 - t0)[m] / nch[m]):8.0f}  "
+              f"span {(t1[m].max() - t0[m].min()):10.0f}  clock {np.mean((t1 - t0)[m] / real[m]) * 0.1:.3f} GHz")
     print(f"   SIMDs seen: {len(np.unique(key))}, waves per SIMD: {np.bincount(np.unique(key, return_inverse=True)[1]).mean():.2f}")

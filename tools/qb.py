@@ -17,6 +17,8 @@ W = {"b255": (4096, 1 << 20, 255), "l101": (1, 1 << 28, 101), "l4095": (1, 1 << 
      "b144": (2048, 1 << 20, 144), "b300": (2048, 1 << 20, 300), "b112": (2048, 1 << 20, 112), "b80": (2048, 1 << 20, 80), "b224": (2048, 1 << 20, 224), "b208": (2048, 1 << 20, 208), "b48": (2048, 1 << 20, 48), "b2": (4096, 1 << 20, 2), "b8": (4096, 1 << 20, 8), "b16": (4096, 1 << 20, 16), "b24": (4096, 1 << 20, 24)}
 MFMA = {"1": True, "0": False}.get(os.environ.get("QB_MFMA"))
 TILED = os.environ.get("QB_TILED") == "1"   # the workgroup-tiled form of the matrix kernel (DSPX_FIR_TILED)
+if os.environ.get("QB_SHARES"):   # 1: fixed shares of runs per wave, 2: runs drawn from the stream's counter at any size
+    dsp_amd.lib().dspx_test_run_shares(int(os.environ["QB_SHARES"]))
 names = sys.argv[1:] or ["b255", "l101", "l4095"]
 def shape_of(nm):
     """A table name, or c<channels>n<samples>t<taps> (n may be 2^k written as 2e<k>)."""
