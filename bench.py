@@ -197,7 +197,7 @@ def run_cwt(args, rank, world, dev, dist, red_dev, ranks_seen=1):
                      "frac": flops / sec / 1e12 / PEAK_FP64_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                      "kernel": "fir_f64_kernel (bank mode, vector pipe)" if args.vector or args.exact else
                                ("fir_f64_mfma4_kernel" if args.tiled else "fir_f64_mfma4wm_kernel (wave-autonomous form)") +
-                               " + fir_f64_kernel (bank mode; rows of >= 56 taps on the matrix pipe)",
+                               " + fir_f64_kernel (bank mode; rows of >= 52 taps on the matrix pipe)",
                      "kernel_ms": kern_ms,
                      "note": "FP64 FMA; algorithmic flops = 2 * sum of per-scale tap counts per input sample"},
         "roofline_other": {"bound": "hbm", "achieved": bytes_alg / sec / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",

@@ -16,7 +16,7 @@ from ._lib import DSPX_FIR_EXACT, DSPX_FIR_FMA, DSPX_FIR_MFMA, DSPX_FIR_TILED, D
 SEED = 0x44535046495236
 # Pipe selection of the default flags (mirrors kMatrixPipeMinTaps in csrc/dspx_common.h):
 # filters of at least MATRIX_PIPE_MIN_TAPS taps run on the FP64 matrix pipe.
-MATRIX_PIPE_MIN_TAPS = 56
+MATRIX_PIPE_MIN_TAPS = 52
 
 
 def device_count() -> int:

@@ -25,7 +25,7 @@ int fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
 constexpr unsigned long long kMaxGrid = (1ull << 24) - 1;
 
 // Taps from which the FP64 matrix pipe is faster than the vector pipe (measured on MI355X).
-constexpr size_t kMatrixPipeMinTaps = 56;
+constexpr size_t kMatrixPipeMinTaps = 52;
 
 inline int check_flags(unsigned flags) {
     if (flags & ~(DSPX_FIR_EXACT | DSPX_FIR_MFMA | DSPX_FIR_VECTOR | DSPX_FIR_TILED))

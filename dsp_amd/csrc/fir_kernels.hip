@@ -825,11 +825,12 @@ struct FirRuns {
     // waves working alone at the end of a launch.  With a counter every wave draws its next run while it works on the
     // current one; the runs that are drawn last -- the tail part of every channel -- are short, so that the waves end
     // within a few chunks of each other.
-    // The workgroups of a launch form `decks` groups (1, 2, 4 or 8) by blockIdx.x % decks; group g is dealt the runs g,
-    // g + decks, ... from a counter of its own (kTicketStride apart).  One counter serves some 40 draws per
-    // microsecond: a launch of several milliseconds stays far below that with a single counter -- and the eight XCDs,
-    // which do not run equally fast, then share the work as they go --, a launch of one millisecond with its few dozen
-    // draws per wave needs eight.
+    // The workgroups of a launch form `decks` groups (1, 2, 4 or 8); group g is dealt the runs g, g + decks, ... from a
+    // counter of its own (kTicketStride apart).  One counter serves some 40 draws per microsecond: a launch of several
+    // milliseconds stays far below that with a single counter, a launch of one millisecond with its few dozen draws
+    // per wave needs eight.  A group is made of workgroups of every XCD (blockIdx.x / 8 % decks: blocks b and b + 8
+    // share an XCD), because the XCDs of a chip hold different clocks: within each group the waves of the fast XCDs
+    // then draw more runs than those of the slow ones, and all groups end together.
     unsigned* tickets;             // per group: [0] the group's next draw minus its waves, [1] its workgroups that have ended
     unsigned decks;
     unsigned lead_runs;            // nchan * runs_per_chan: runs [0, lead_runs) are the long ones
@@ -979,15 +980,16 @@ __global__ __launch_bounds__(kBlock, RESIDENT) void fir_f64_mfma4w_kernel(const 
     const unsigned long long r_begin = __builtin_amdgcn_s_memrealtime();
 #endif
     // Drawn runs: this workgroup's group, its counters, its waves, and this wave's place among them.
-    const unsigned decks = rn.decks;                       // (a power of two that divides the grid)
-    const unsigned deck = blockIdx.x & (decks - 1);
+    const unsigned decks = rn.decks;                       // (a power of two; 8 * decks divides the grid)
+    const unsigned deck = (blockIdx.x >> 3) & (decks - 1);
     unsigned* const tickets = rn.tickets != nullptr ? rn.tickets + deck * kTicketStride : nullptr;
     const unsigned deck_blocks = gridDim.x / decks;
     const unsigned deck_waves = deck_blocks * (kBlock / 64);
+    const unsigned deck_place = ((blockIdx.x >> 3) / decks) * 8 + (blockIdx.x & 7);   // this workgroup among its group's
     const int npairs = (kHalo + kChunk - qlo) / 2;   // sample pairs of a run's first window
     static_assert(kBodyIters + kHaloIters >= kFirstIters, "a first window fits in the registers of a body and a halo");
     bool window_ready = false;   // the image holds the run's first window already (fetched during the run before)
-    for (unsigned run = tickets != nullptr ? decks * ((blockIdx.x / decks) * (kBlock / 64) + wave) + deck
+    for (unsigned run = tickets != nullptr ? decks * (deck_place * (kBlock / 64) + wave) + deck
                                            : blockIdx.x * (kBlock / 64) + wave;
          run < rn.total_runs;) {
         const RunSpan span = run_span(rn, run);
@@ -1701,20 +1703,24 @@ static std::atomic<int> g_share_mode{0};   // test hook (dspx_test_run_shares): 
 // waves end together, and never fewer than kMinRun chunks per run unless the input is too small to occupy every
 // wave that way (a run's first window is fetched with its halo, the only samples read twice).
 //
-// With `tickets` (a counter pair of the launch's stream) and an input of kDrawnFrom chunks per wave or more, the runs
+// With `tickets` (the counter set of the launch's stream) and an input of kDrawnFrom chunks per wave or more, the runs
 // are handed out in order instead (see FirRuns): long runs over the first three quarters of the input -- of every
 // channel when there are few channels, the first three quarters of the channels otherwise --, about kLeadPerWave per
 // wave, then runs an eighth as long over the rest.
+constexpr unsigned long long kDrawnFrom = 32;
+static bool large_enough_to_draw(unsigned nchan, long long n, unsigned max_waves, unsigned long long kChunk) {
+    const unsigned long long cpc = ((unsigned long long)n + kChunk - 1) / kChunk;
+    return cpc <= 0x7fffffffull && (cpc * nchan / max_waves >= kDrawnFrom || g_share_mode.load(std::memory_order_relaxed) == 2);
+}
 static bool plan_runs(unsigned nchan, long long n, unsigned max_waves, FirRuns& rn, unsigned long long kChunk,
                       unsigned long long fixed_run = 0, unsigned* tickets = nullptr) {
-    constexpr unsigned long long kRunsPerWave = 8, kMinRun = 32, kDrawnFrom = 32, kLeadPerWave = 6, kTailDiv = 8, kFewChannels = 16;
+    constexpr unsigned long long kRunsPerWave = 8, kMinRun = 32, kLeadPerWave = 6, kTailDiv = 8, kFewChannels = 16;
     const unsigned long long cpc = ((unsigned long long)n + kChunk - 1) / kChunk, total_chunks = cpc * nchan;
     unsigned long long want = (total_chunks + kRunsPerWave * max_waves - 1) / (kRunsPerWave * max_waves);
     if (want < kMinRun) want = std::min(kMinRun, std::max<unsigned long long>(1, total_chunks / max_waves));
     if (fixed_run) want = fixed_run;   // (a kernel that carries nothing from chunk to chunk)
     const unsigned long long per_wave = total_chunks / max_waves;
-    const bool drawn = tickets != nullptr && !fixed_run && cpc <= 0x7fffffffull &&
-                       (per_wave >= kDrawnFrom || g_share_mode.load(std::memory_order_relaxed) == 2);
+    const bool drawn = tickets != nullptr && !fixed_run && large_enough_to_draw(nchan, n, max_waves, kChunk);
     unsigned long long lead_nchan = nchan, lead_chunks = cpc, tail_run = 0;
     if (drawn) {
         want = std::max(kMinRun, per_wave * 3 / 4 / kLeadPerWave);
@@ -1858,18 +1864,20 @@ static void launch_mfma_variant(const double* taps, const double* x, const doubl
             const bool several = steps > 2 * M4Geo<2>::kStageSteps + 1;   // several windows per chunk: runs of one chunk
             const unsigned max_waves = compute_units() * ((big || several) ? 2u : 4u) * kWaves;
             FirRuns rn;
-            if (plan_runs(shape.total_tiles / shape.tiles_per_chan, shape.n, max_waves, rn, (big || several) ? 1024 : 512, several ? 1 : 0,
-                          several ? nullptr : ticket_set(stream))) {
+            const unsigned nchan = shape.total_tiles / shape.tiles_per_chan, chunk = (big || several) ? 1024 : 512;
+            unsigned* const tickets = !several && large_enough_to_draw(nchan, shape.n, max_waves, chunk) ? ticket_set(stream) : nullptr;
+            if (plan_runs(nchan, shape.n, max_waves, rn, chunk, several ? 1 : 0, tickets)) {
                 unsigned wgs = std::min((rn.total_runs + kWaves - 1) / kWaves, max_waves / kWaves);
                 if (several) wgs = (wgs + 7) / 8 * 8;   // (its waves are addressed by XCD)
                 if (rn.tickets != nullptr) {
-                    wgs = std::max(wgs / kMaxRunDecks * kMaxRunDecks, kMaxRunDecks);   // (groups of equal size)
                     // how long the launch will take, roughly (60 TFLOP/s, 5 TB/s), and the draws per microsecond that makes
-                    const double outputs = (double)shape.n * (shape.total_tiles / shape.tiles_per_chan);
+                    const double outputs = (double)shape.n * nchan;
                     const double micros = std::max(outputs * 2.0 * shape.ntaps / 60e6, outputs * 16.0 / 5e6);
                     constexpr double kDrawsPerMicro = 10.0;   // per counter
                     rn.decks = 1;
                     while (rn.decks < kMaxRunDecks && rn.total_runs > kDrawsPerMicro * micros * rn.decks) rn.decks *= 2;
+                    while (rn.decks > 1 && wgs < 8 * rn.decks) rn.decks /= 2;   // (a group has workgroups of every XCD)
+                    wgs = std::max(wgs / (8 * rn.decks) * (8 * rn.decks), 8u);   // (groups of equal size)
                 }
                 const dim3 wgrid(wgs);
                 if (steps < kBigFrom)

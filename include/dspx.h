@@ -40,7 +40,7 @@ typedef enum dspx_status {
 
 /* Arithmetic mode of the filter kernels (the `flags` argument). */
 #define DSPX_FIR_FMA 0u    /* default: fused multiply-adds, the library picks the pipe: the FP64 matrix
-                              pipe (Toeplitz-block v_mfma_f64_4x4x4_4b_f64) for filters of 56 taps or more,
+                              pipe (Toeplitz-block v_mfma_f64_4x4x4_4b_f64) for filters of 52 taps or more,
                               the vector pipe (v_fma_f64, taps strictly ascending) below                     */
 #define DSPX_FIR_EXACT 1u  /* separately rounded multiply then add per tap, taps ascending, on the vector
                               pipe: bit-identical to the reference loop compiled without FMA contraction
