@@ -796,7 +796,10 @@ __global__ __launch_bounds__(kBlock, OB == 4 ? 2 : 4) void fir_f64_mfma4_kernel(
 //     output, where the workgroup-tiled form re-reads 11 %);
 //   * results are transposed through the body's place in the wave's own image (dead once the products are done),
 //     read back in output order, 512 contiguous bytes per store instruction, and stored one chunk late, after the
-//     next chunk's loads and first LDS reads have been issued.
+//     next chunk's loads and first LDS reads have been issued;
+//   * a change of run costs what a change of chunk costs: a run's last chunk fetches the whole first window of the
+//     wave's next run while its products run.  On large inputs that next run is drawn from a device counter of the
+//     launch's stream (FirRuns below), on small ones and under stream capture every wave has a fixed share.
 // Per chunk a wave issues, besides its matrix instructions, 4 (8) loads, 8 (16) stores, about 30 (45) LDS instructions
 // and about two dozen vector instructions, and waits for nobody but itself: between the last matrix instruction of a
 // chunk and the first of the next lies one LDS round trip.  The 1024-output chunks halve the LDS reads per matrix
@@ -821,9 +824,9 @@ struct FirRuns {
     unsigned chunks_per_chan;      // ceil(n / outputs per chunk)
     unsigned total_runs;           // lead_runs + nchan * tail_runs_per_chan
     // Runs handed out in order by a counter (tickets != nullptr; otherwise wave w takes runs w, w + waves, ...).  The
-    // waves of a SIMD are served oldest first and progress at different speeds, so equal shares leave the youngest
-    // waves working alone at the end of a launch.  With a counter every wave draws its next run while it works on the
-    // current one; the runs that are drawn last -- the tail part of every channel -- are short, so that the waves end
+    // waves of a chip do not progress equally fast -- its eight XCDs hold clocks 5-7 % apart under this kernel, and a
+    // SIMD serves its waves oldest first --, so equal shares end with the slowest.  With a counter every wave draws
+    // its next run while it works on the current one; the runs that are drawn last are short, so that the waves end
     // within a few chunks of each other.
     // The workgroups of a launch form `decks` groups (1, 2, 4 or 8); group g is dealt the runs g, g + decks, ... from a
     // counter of its own (kTicketStride apart).  One counter serves some 40 draws per microsecond: a launch of several
