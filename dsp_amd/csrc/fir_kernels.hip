@@ -888,8 +888,8 @@ __device__ __forceinline__ unsigned long long stamp() {
 
 // OB: a segment is 16 * OB consecutive outputs (4 * OB row blocks, one accumulator each), a chunk 16 segments.
 // HG: pad groups (of one segment's length) in front of the samples of a chunk.  <HG 9, OB 2>: 512-output chunks, 288
-// halo slots, four workgroups per CU (116 VGPRs); <5, 4> and <9, 4>: 1024-output chunks, 320 / 576 halo slots (up to
-// 313 / 569 taps), two workgroups per CU (182 / 206 VGPRs).
+// halo slots, four workgroups per CU (128 VGPRs); <5, 4> and <9, 4>: 1024-output chunks, 320 / 576 halo slots (up to
+// 313 / 569 taps), two workgroups per CU (192 / 208 VGPRs).
 template <int RESIDENT, int HG, int OB>
 __global__ __launch_bounds__(kBlock, RESIDENT) void fir_f64_mfma4w_kernel(const double* __restrict__ taps,
                                                                            const double* __restrict__ x,
@@ -1048,6 +1048,11 @@ __global__ __launch_bounds__(kBlock, RESIDENT) void fir_f64_mfma4w_kernel(const 
 #pragma unroll
                     for (int i = 0; i < kBodyIters; ++i)
                         R[i] = stream_load(scalar_base(reinterpret_cast<const dvec2*>(xn) + 64 * i) + (unsigned)lane);
+                } else {
+                    // (never read on this path; "defined" without an instruction, or the compiler clears the sixteen
+                    // registers at the top of every chunk -- on the vector unit, which the matrix pipe then waits for)
+#pragma unroll
+                    for (int i = 0; i < kBodyIters; ++i) asm volatile("" : "=v"(R[i]));
                 }
             } else {
                 next_run = tickets != nullptr ? decks * (deck_waves + (unsigned)__builtin_amdgcn_readfirstlane((int)drawn)) + deck

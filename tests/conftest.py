@@ -15,6 +15,14 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    # DSPX_TEST_RUN_SHARES=1|2 runs the whole suite with the matrix kernels' runs in fixed shares / drawn from the
+    # stream's counters whatever the input's size (the library's test hook dspx_test_run_shares; results must not
+    # depend on it -- tests that set the hook themselves restore the default, 0, when they end)
+    mode = os.environ.get("DSPX_TEST_RUN_SHARES")
+    if mode:
+        import dsp_amd
+
+        dsp_amd.lib().dspx_test_run_shares(int(mode))
 
 
 @pytest.fixture(scope="session")
