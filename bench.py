@@ -654,7 +654,7 @@ def main() -> None:
         steps_of_four = (numtaps + 2) // 4 + 1
         kernel_name = ("fir_f64_kernel (v_fma_f64)" if not matrix else
                        "fir_f64_mfma4_kernel (v_mfma_f64_4x4x4_4b_f64, workgroup-tiled form)" if args.tiled else
-                       "fir_f64_mfma4w_kernel (v_mfma_f64_4x4x4_4b_f64, wave-autonomous form, one window per chunk)"
+                       "fir_f64_mfma4w_kernel (v_mfma_f64_4x4x4_4b_f64, wave-autonomous form, one window per chunk, runs of chunks drawn from the stream's device counters)"
                        if steps_of_four <= 143 else
                        "fir_f64_mfma4wm_kernel (v_mfma_f64_4x4x4_4b_f64, wave-autonomous form, several windows per chunk)")
         outputs_per_launch = nchan * n_local
