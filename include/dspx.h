@@ -182,7 +182,11 @@ DSPX_API long dspx_fir_plan(size_t nchan, size_t n, int ngpus, dspx_piece* out, 
  * that precede d_x[c*x_stride] (d_hist[c*hist_stride + ntaps-2] is x[-1]); NULL is the
  * reference's zero initial state.  History has no counterpart in the reference (its
  * lfilter keeps no state, dsp.hpp:356-365); it is what makes segment sharding and
- * chunked streaming produce the same samples as one long call. */
+ * chunked streaming produce the same samples as one long call.
+ * Streams: any number may be in use at once.  For large inputs the matrix-pipe kernels hand their work out through
+ * a few device counters that belong to the launch's stream (64 sets per GPU inside the library, left at zero by every
+ * launch); hipStreamPerThread, hipStreamLegacy, launches recorded under stream capture and streams beyond the 64th
+ * get fixed shares of work per wave instead -- a few per cent slower on batched inputs, the same results. */
 DSPX_API int dspx_fir_f64_dev(const double* d_taps, size_t ntaps, const double* d_x, size_t x_stride, const double* d_hist,
                      size_t hist_stride, double* d_y, size_t y_stride, size_t nchan, size_t n, unsigned flags,
                      void* stream);
