@@ -1297,9 +1297,14 @@ __global__ __launch_bounds__(kBlock, RESIDENT) void fir_f64_mfma4wm_kernel(const
     static_assert(!BANK || (kChunk + 1) + ((kChunk + 1) >> G::kShift) < (kImgGroups - kHaloGroups) * G::kPadStep,
                   "bank mode reads c[q + 2] of a chunk's last values inside the image");
     __shared__ double2 lds[(kBlock / 64) * (kTapPairs + kImgPairs)];
+    __shared__ unsigned waves_ended;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (rn.tickets != nullptr) {   // (drawn chunks: the workgroup counts its waves as they end)
+        if (tid == 0) waves_ended = 0;
+        __syncthreads();
+    }
     double* const tapw = reinterpret_cast<double*>(lds + wave * (kTapPairs + kImgPairs));
     dvec2* const imgw = reinterpret_cast<dvec2*>(lds + wave * (kTapPairs + kImgPairs) + kTapPairs);
     double* const imgd = reinterpret_cast<double*>(imgw);
@@ -1431,6 +1436,20 @@ __global__ __launch_bounds__(kBlock, RESIDENT) void fir_f64_mfma4wm_kernel(const
     };
     unsigned stretch = 0, place = in_xcd;  // `stretch`: the first run of the stretch the wave is in
     unsigned run = run_at(stretch, place);
+    // Drawn chunks (rn.tickets, as in fir_f64_mfma4w_kernel: counter groups made of workgroups of every XCD): the wave's
+    // first two chunks are fixed, every later one is drawn from its group's counter a whole chunk before it is needed
+    // (the chunk after the current one must be known when the current one's last window starts).
+    const unsigned decks = rn.decks;
+    const unsigned deck = (blockIdx.x >> 3) & (decks - 1);
+    unsigned* const tickets = rn.tickets != nullptr ? rn.tickets + deck * kTicketStride : nullptr;
+    const unsigned deck_blocks = gridDim.x / decks, deck_waves = deck_blocks * (kBlock / 64);
+    const unsigned deck_wave = (((blockIdx.x >> 3) / decks) * 8 + (blockIdx.x & 7)) * (kBlock / 64) + wave;
+    unsigned known_next = 0, drawn = 0;
+    if (tickets != nullptr) {
+        run = decks * deck_wave + deck;
+        known_next = decks * (deck_waves + deck_wave) + deck;
+        if (lane == 0) drawn = __hip_atomic_fetch_add(tickets, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     if (run < rn.total_runs) {
         // The chunk in hand: its channel (row), `pos` = the sample position of its first value, `yk` / `opos` = where its
         // first output goes and which output of the channel that is.
@@ -1468,7 +1487,7 @@ __global__ __launch_bounds__(kBlock, RESIDENT) void fir_f64_mfma4wm_kernel(const
             const bool last_window = e0 + steps >= cur.total_steps;
             // the window after this one: the chunk's next, the first of the run's next chunk, or of the wave's next run
             const unsigned next_place = place + 1 == per_xcd ? 0 : place + 1;
-            const unsigned next_run = run_at(stretch + per_stretch, next_place);
+            const unsigned next_run = tickets != nullptr ? known_next : run_at(stretch + per_stretch, next_place);
             const bool have_next = !last_window || left_in_run > 0 || next_run < rn.total_runs;
             const double *n_xc = xc, *n_hc = hc;
             double* n_yk = yk;
@@ -1578,7 +1597,14 @@ __global__ __launch_bounds__(kBlock, RESIDENT) void fir_f64_mfma4wm_kernel(const
                 pend_yt = yk;
                 pend_left = negative(left - kOutputs) ? (int)left : kOutputs;
                 stores_due = true;
-                if (left_in_run == 0) run = next_run, stretch += per_stretch, place = next_place;
+                if (left_in_run == 0) {
+                    run = next_run, stretch += per_stretch, place = next_place;
+                    if (tickets != nullptr && have_next) {
+                        known_next = decks * (2 * deck_waves + (unsigned)__builtin_amdgcn_readfirstlane((int)drawn)) + deck;
+                        if (known_next < rn.total_runs && lane == 0)   // (a wave stops drawing at its first number past the end)
+                            drawn = __hip_atomic_fetch_add(tickets, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
             }
             if (!have_next) break;
             xc = n_xc, hc = n_hc, yk = n_yk, pos = n_pos, opos = n_opos, left_in_run = n_left, e0 = n_e0;
@@ -1586,6 +1612,15 @@ __global__ __launch_bounds__(kBlock, RESIDENT) void fir_f64_mfma4wm_kernel(const
         }
     }
     if (stores_due) store_chunk();
+    if (tickets != nullptr) asm volatile("" ::"v"(drawn));   // (a draw that nobody read has arrived before the wave counts itself)
+    if (tickets != nullptr && lane == 0) {
+        // the last workgroup of the group to end leaves its counters at zero for the next launch on this stream
+        if (__hip_atomic_fetch_add(&waves_ended, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == kBlock / 64 - 1 &&
+            __hip_atomic_fetch_add(tickets + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == deck_blocks - 1) {
+            __hip_atomic_store(tickets, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(tickets + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1830,6 +1865,21 @@ void forget_stream(hipStream_t stream) {
         if (d.taken[i] && d.streams[i] == stream) d.taken[i] = false;
 }
 
+// Drawn chunks for the several-windows kernel (runs of one chunk each): takes the stream's counters when the input is
+// large enough, picks the number of counter groups from the expected draw rate and makes the grid a multiple of 8 per
+// group.  `ntaps`: the (mean) filter length, for the estimate of the launch's duration.
+static void draw_chunks(FirRuns& rn, unsigned& wgs, unsigned nchan, long long n, double ntaps, unsigned* tickets) {
+    constexpr unsigned kWaves = kBlock / 64;
+    if (tickets == nullptr || wgs < 8 || rn.total_runs < 4ull * wgs * kWaves) return;   // (two fixed runs per wave, then at least as many drawn)
+    const double outputs = (double)n * nchan;
+    const double micros = std::max(outputs * 2.0 * ntaps / 60e6, outputs * 16.0 / 5e6);
+    rn.decks = 1;
+    while (rn.decks < kMaxRunDecks && rn.total_runs > 10.0 * micros * rn.decks) rn.decks *= 2;
+    while (rn.decks > 1 && wgs < 8 * rn.decks) rn.decks /= 2;
+    wgs = std::max(wgs / (8 * rn.decks) * (8 * rn.decks), 8u);
+    rn.tickets = tickets;
+}
+
 // The several-windows kernel as the wavelet bank runs it: 1024-value chunks, 576 halo slots (143 steps per window).
 constexpr int kWaveBankHG = 9, kWaveBankOB = 4;
 
@@ -1850,7 +1900,9 @@ static void launch_mfma_variant(const double* taps, const double* x, const doubl
         const unsigned max_waves = compute_units() * 2u * kWaves;
         FirRuns rn;
         if (!tiled && rows > 0 && plan_runs(rows, shape.n, max_waves, rn, M4Geo<kWaveBankOB>::kWaveOut - 2, 1)) {
-            const unsigned wgs = (std::min((rn.total_runs + kWaves - 1) / kWaves, max_waves / kWaves) + 7) / 8 * 8;
+            unsigned wgs = (std::min((rn.total_runs + kWaves - 1) / kWaves, max_waves / kWaves) + 7) / 8 * 8;
+            if (large_enough_to_draw(rows, shape.n, max_waves, M4Geo<kWaveBankOB>::kWaveOut - 2))
+                draw_chunks(rn, wgs, rows, shape.n, 550.0, ticket_set(stream));
             if (vec2)
                 hipLaunchKernelGGL((fir_f64_mfma4wm_kernel<2, kWaveBankHG, kWaveBankOB, true, true>), dim3(wgs), block, 0, stream, taps, x, hist, y, bank, shape, rn);
             else
@@ -1873,11 +1925,18 @@ static void launch_mfma_variant(const double* taps, const double* x, const doubl
             const unsigned max_waves = compute_units() * ((big || several) ? 2u : 4u) * kWaves;
             FirRuns rn;
             const unsigned nchan = shape.total_tiles / shape.tiles_per_chan, chunk = (big || several) ? 1024 : 512;
-            unsigned* const tickets = !several && large_enough_to_draw(nchan, shape.n, max_waves, chunk) ? ticket_set(stream) : nullptr;
-            if (plan_runs(nchan, shape.n, max_waves, rn, chunk, several ? 1 : 0, tickets)) {
+            // The several-windows kernel draws its chunks only for filters of up to kDrawnChunkTaps taps: beyond, the chip
+            // sits at its full clock on every XCD and there is nothing to balance, while chunks that are no longer dealt
+            // XCD by XCD cost HBM reads (4095 taps: 4.1 x the algorithmic bytes instead of 1.04 x; 1023 taps: 2.0 x
+            // instead of 1.03 x, for +1.2 % of throughput -- runs of two or four chunks per draw read no less).
+            constexpr int kDrawnChunkTaps = 3072;
+            const bool may_draw = large_enough_to_draw(nchan, shape.n, max_waves, chunk) && (!several || shape.ntaps <= kDrawnChunkTaps);
+            unsigned* const tickets = may_draw ? ticket_set(stream) : nullptr;
+            if (plan_runs(nchan, shape.n, max_waves, rn, chunk, several ? 1 : 0, several ? nullptr : tickets)) {
                 unsigned wgs = std::min((rn.total_runs + kWaves - 1) / kWaves, max_waves / kWaves);
                 if (several) wgs = (wgs + 7) / 8 * 8;   // (its waves are addressed by XCD)
-                if (rn.tickets != nullptr) {
+                if (several && tickets != nullptr) draw_chunks(rn, wgs, nchan, shape.n, (double)shape.ntaps, tickets);
+                if (rn.tickets != nullptr && !several) {
                     // how long the launch will take, roughly (60 TFLOP/s, 5 TB/s), and the draws per microsecond that makes
                     const double outputs = (double)shape.n * nchan;
                     const double micros = std::max(outputs * 2.0 * shape.ntaps / 60e6, outputs * 16.0 / 5e6);

@@ -1,5 +1,6 @@
-"""GPU tests of how the wave-autonomous FIR kernels hand out their runs of chunks (dsp_amd/csrc/fir_kernels.hip,
-FirRuns): in fixed shares per wave, or drawn from the counters of the launch's stream.  Which wave computes a chunk
+"""GPU tests of how the wave-autonomous FIR kernels (one window per chunk, several windows per chunk, wavelet bank)
+hand out their runs of chunks (dsp_amd/csrc/fir_kernels.hip, FirRuns): in fixed shares per wave, or drawn from the
+counters of the launch's stream.  Which wave computes a chunk
 never changes the chunk's arithmetic, so the two must agree bit for bit, launch after launch (the counters are left at
 zero by the kernel itself), on several streams at once, and on more streams than a device has sets of counters (the
 later ones keep the fixed shares until a set is given back).  Calls go through the C ABI; dspx_test_run_shares is the library's test hook (exported,
@@ -74,6 +75,51 @@ def test_default_draw_on_large_inputs(env, nchan, log2n, nt):
         y.zero_()
         dsp.fir_device(taps, x, out=y)
         assert dsp.checksum(y) == want
+
+
+@pytest.mark.parametrize("nchan,log2n,nt", [(64, 20, 700), (1, 26, 1023), (512, 17, 2047), (16, 22, 570)])
+def test_several_windows_kernel_draws_its_chunks(env, nchan, log2n, nt):
+    """Filters of 570 to 3072 taps (several windows per chunk): the chunks after a wave's first two are drawn.  Three
+    launches in a row against fixed shares, bit for bit."""
+    dsp, torch, hook = env
+    taps = torch.from_numpy(dsp.firwin(nt, 0.2)).cuda()
+    x = torch.empty((nchan, 1 << log2n), dtype=torch.float64, device="cuda")
+    dsp.fill_splitmix(x)
+    hook(1)
+    want = dsp.checksum(dsp.fir_device(taps, x))
+    y = torch.empty_like(x)
+    for mode in (0, 2):
+        hook(mode)
+        for _ in range(3):
+            y.zero_()
+            dsp.fir_device(taps, x, out=y)
+            assert dsp.checksum(y) == want
+    hook(0)
+
+
+def test_wavelet_bank_draws_its_chunks(env):
+    """The wavelet bank on the several-windows kernel: a row's bits depend on how the row is cut into chunks, never on
+    which wave computes a chunk -- drawn chunks against fixed shares, bit for bit, apply after apply."""
+    dsp, torch, hook = env
+    psi, wx = dsp.integrate_wavelet(10)
+    n = 1 << 20
+    sig = torch.empty(n, dtype=torch.float64, device="cuda")
+    dsp.fill_splitmix(sig)
+    for scales in (np.arange(1, 66, dtype=np.float64), np.array([3.5, 9.0, 20.25, 41.0, 64.0])):
+        bank = dsp.CwtBank(scales, psi, wx)
+        out = torch.empty((bank.rows, n), dtype=torch.float64, device="cuda")
+        hook(1)
+        bank.apply(sig, out=out)
+        want = out.clone()
+        for mode in (0, 2):
+            hook(mode)
+            for _ in range(2):
+                out.zero_()
+                bank.apply(sig, out=out)
+                both_nan = torch.isnan(out) & torch.isnan(want)
+                assert bool(((out.view(torch.int64) == want.view(torch.int64)) | both_nan).all())
+        hook(0)
+        bank.close()
 
 
 def test_streams_have_counters_of_their_own(env):

@@ -18,16 +18,19 @@ streams = [torch.cuda.Stream() for _ in range(6)]
 bad = 0
 pending = []   # (drawn result, fixed result, description), checked in batches so that launches overlap
 for case in range(cases):
-    nt = int(rng.choice([52, 57, 63, 101, 128, 189, 190, 255, 313, 314, 400, 569]))
-    kind = rng.integers(4)
+    nt = int(rng.choice([52, 57, 63, 101, 128, 189, 190, 255, 313, 314, 400, 569, 570, 700, 1023]))
+    kind = rng.integers(4) if nt < 570 else 4
     if kind == 0:
         nchan, n = 1, int(rng.integers(1, 1 << 23))
     elif kind == 1:
         nchan, n = int(rng.integers(2, 16)), int(rng.integers(1, 1 << 20))
     elif kind == 2:
         nchan, n = int(rng.integers(16, 400)), int(rng.integers(1, 1 << 16))
-    else:
+    elif kind == 3:
         nchan, n = int(rng.integers(400, 5000)), int(rng.integers(1, 3000))
+    else:   # the several-windows kernel draws from four chunks per wave on: 2^23 samples and more
+        nchan = int(rng.choice([1, 3, 20, 300]))
+        n = int(rng.integers(1 << 23, 1 << 24)) // nchan
     n += n & 1   # (16-byte aligned rows: the wave-autonomous kernels)
     taps = torch.from_numpy(dsp_amd.firwin(nt, 0.3)).cuda()
     x = torch.empty((nchan, n), dtype=torch.float64, device="cuda")
