@@ -1259,6 +1259,12 @@ __global__ __launch_bounds__(kBlock, RESIDENT) void fir_f64_mfma4w_kernel(const 
 // its own).  While the products of one window run, the samples and taps of the next -- the next chunk's first
 // window after a chunk's last -- are in flight into registers; between two windows lies one LDS round trip.  Same
 // products in the same order as fir_f64_mfma4_kernel: same bits.
+// Large inputs with filters of up to 3072 taps, and wavelet banks, give that order up for another gain: the XCDs of a
+// chip hold clocks a few per cent apart, so with equal shares the launch ends with the slowest.  There a wave's chunks
+// after its first two are drawn from the counters of the launch's stream (FirRuns::tickets), a whole chunk before
+// they are needed; neighbouring chunks then land on any XCD and their overlapping reads meet in HBM (1023 taps: 2 x
+// the algorithmic read bytes for +1.2 % of throughput; the 65-scale bank 3.6 GB instead of 0.4 GB per launch for
+// +1.4 %).  Longer filters run at the chip's full clock on every XCD and keep the fixed order.
 //
 // BANK (the wavelet path, reference dsp.hpp:1136-1217): one input, rows of taps of different lengths.  A unit of work is
 // a chunk of one row: 1024 values of c[t] = sum_k taps_r[k] * x[t + advance_r - k] (zeros outside [0, n)), of which the

@@ -103,9 +103,10 @@ def test_wavelet_bank_draws_its_chunks(env):
     dsp, torch, hook = env
     psi, wx = dsp.integrate_wavelet(10)
     n = 1 << 20
-    sig = torch.empty(n, dtype=torch.float64, device="cuda")
-    dsp.fill_splitmix(sig)
-    for scales in (np.arange(1, 66, dtype=np.float64), np.array([3.5, 9.0, 20.25, 41.0, 64.0])):
+    buf = torch.empty(n + 2, dtype=torch.float64, device="cuda")
+    dsp.fill_splitmix(buf)
+    for scales, sig in ((np.arange(1, 66, dtype=np.float64), buf[:n]), (np.array([3.5, 9.0, 20.25, 41.0, 64.0]), buf[:n]),
+                        (np.arange(20, 66, dtype=np.float64), buf[1:n + 1])):   # (the last signal is only 8-byte aligned)
         bank = dsp.CwtBank(scales, psi, wx)
         out = torch.empty((bank.rows, n), dtype=torch.float64, device="cuda")
         hook(1)
