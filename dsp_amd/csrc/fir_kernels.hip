@@ -1262,9 +1262,10 @@ __global__ __launch_bounds__(kBlock, RESIDENT) void fir_f64_mfma4w_kernel(const 
 // Large inputs with filters of up to 3072 taps, and wavelet banks, give that order up for another gain: the XCDs of a
 // chip hold clocks a few per cent apart, so with equal shares the launch ends with the slowest.  There a wave's chunks
 // after its first two are drawn from the counters of the launch's stream (FirRuns::tickets), a whole chunk before
-// they are needed; neighbouring chunks then land on any XCD and their overlapping reads meet in HBM (1023 taps: 2 x
-// the algorithmic read bytes for +1.2 % of throughput; the 65-scale bank 3.6 GB instead of 0.4 GB per launch for
-// +1.4 %).  Longer filters run at the chip's full clock on every XCD and keep the fixed order.
+// they are needed; neighbouring chunks then land on any XCD and their overlapping reads miss its L2 (measured as L2
+// fetches from the fabric, which the infinity cache or HBM serves: 1023 taps 2 x the algorithmic read bytes for
+// +1.2 % of throughput; the 65-scale bank 3.6 GB instead of 0.4 GB per launch for +1.4 %).  Longer filters run at
+// the chip's full clock on every XCD and keep the fixed order.
 //
 // BANK (the wavelet path, reference dsp.hpp:1136-1217): one input, rows of taps of different lengths.  A unit of work is
 // a chunk of one row: 1024 values of c[t] = sum_k taps_r[k] * x[t + advance_r - k] (zeros outside [0, n)), of which the
@@ -1756,10 +1757,17 @@ static std::atomic<int> g_share_mode{0};   // test hook (dspx_test_run_shares): 
 // are handed out in order instead (see FirRuns): long runs over the first three quarters of the input -- of every
 // channel when there are few channels, the first three quarters of the channels otherwise --, about kLeadPerWave per
 // wave, then runs an eighth as long over the rest.
-constexpr unsigned long long kDrawnFrom = 32;
-static bool large_enough_to_draw(unsigned nchan, long long n, unsigned max_waves, unsigned long long kChunk) {
+// (Measured: at 64 chunks per wave -- launches of half a millisecond to a millisecond -- drawn runs are 1-4 % slower than
+// fixed shares, because the long runs a wave commits to when it starts are most of its work; at 128 they are equal
+// or faster.)
+constexpr unsigned long long kDrawnFrom = 128;
+// The several-windows kernel draws single chunks from a wave's third chunk on, so it adapts from the start: it draws
+// from kDrawnChunksFrom chunks per wave.
+constexpr unsigned long long kDrawnChunksFrom = 32;
+static bool large_enough_to_draw(unsigned nchan, long long n, unsigned max_waves, unsigned long long kChunk,
+                                 unsigned long long from = kDrawnFrom) {
     const unsigned long long cpc = ((unsigned long long)n + kChunk - 1) / kChunk;
-    return cpc <= 0x7fffffffull && (cpc * nchan / max_waves >= kDrawnFrom || g_share_mode.load(std::memory_order_relaxed) == 2);
+    return cpc <= 0x7fffffffull && (cpc * nchan / max_waves >= from || g_share_mode.load(std::memory_order_relaxed) == 2);
 }
 static bool plan_runs(unsigned nchan, long long n, unsigned max_waves, FirRuns& rn, unsigned long long kChunk,
                       unsigned long long fixed_run = 0, unsigned* tickets = nullptr) {
@@ -1907,7 +1915,7 @@ static void launch_mfma_variant(const double* taps, const double* x, const doubl
         FirRuns rn;
         if (!tiled && rows > 0 && plan_runs(rows, shape.n, max_waves, rn, M4Geo<kWaveBankOB>::kWaveOut - 2, 1)) {
             unsigned wgs = (std::min((rn.total_runs + kWaves - 1) / kWaves, max_waves / kWaves) + 7) / 8 * 8;
-            if (large_enough_to_draw(rows, shape.n, max_waves, M4Geo<kWaveBankOB>::kWaveOut - 2))
+            if (large_enough_to_draw(rows, shape.n, max_waves, M4Geo<kWaveBankOB>::kWaveOut - 2, kDrawnChunksFrom))
                 draw_chunks(rn, wgs, rows, shape.n, 550.0, ticket_set(stream));
             if (vec2)
                 hipLaunchKernelGGL((fir_f64_mfma4wm_kernel<2, kWaveBankHG, kWaveBankOB, true, true>), dim3(wgs), block, 0, stream, taps, x, hist, y, bank, shape, rn);
@@ -1936,7 +1944,8 @@ static void launch_mfma_variant(const double* taps, const double* x, const doubl
             // XCD by XCD cost HBM reads (4095 taps: 4.1 x the algorithmic bytes instead of 1.04 x; 1023 taps: 2.0 x
             // instead of 1.03 x, for +1.2 % of throughput -- runs of two or four chunks per draw read no less).
             constexpr int kDrawnChunkTaps = 3072;
-            const bool may_draw = large_enough_to_draw(nchan, shape.n, max_waves, chunk) && (!several || shape.ntaps <= kDrawnChunkTaps);
+            const bool may_draw = large_enough_to_draw(nchan, shape.n, max_waves, chunk, several ? kDrawnChunksFrom : kDrawnFrom) &&
+                                  (!several || shape.ntaps <= kDrawnChunkTaps);
             unsigned* const tickets = may_draw ? ticket_set(stream) : nullptr;
             if (plan_runs(nchan, shape.n, max_waves, rn, chunk, several ? 1 : 0, several ? nullptr : tickets)) {
                 unsigned wgs = std::min((rn.total_runs + kWaves - 1) / kWaves, max_waves / kWaves);
@@ -2086,7 +2095,7 @@ hipError_t launch_checksum(const double* yv, unsigned long long n, unsigned long
 // Test hooks (not part of the C ABI, include/dspx.h does not declare them; results do not depend on them).
 // dspx_test_run_shares: 1 makes every launch of the wave-autonomous kernels use fixed shares of runs per wave, as
 // launches under stream capture do; 2 makes them draw their runs from the stream's counter whatever the input's
-// size (by default only inputs of 32 chunks per wave or more do); 0 restores the default.  Returns the previous
+// size (by default only inputs of 128 chunks per wave or more do); 0 restores the default.  Returns the previous
 // setting.  dspx_test_forget_stream: gives an idle stream's counters back (what the library does for its own
 // streams before it destroys them).  dspx_test_run_plan: the runs plan_runs() cuts an input into, decoded as the kernels decode them
 // (chan, first chunk, end chunk per run); returns the number of runs, or -1 when the plan does not fit `cap`.

@@ -5,7 +5,7 @@ never changes the chunk's arithmetic, so the two must agree bit for bit, launch 
 zero by the kernel itself), on several streams at once, and on more streams than a device has sets of counters (the
 later ones keep the fixed shares until a set is given back).  Calls go through the C ABI; dspx_test_run_shares is the library's test hook (exported,
 not part of include/dspx.h): 1 forces fixed shares, 2 draws whatever the input's size, 0 is the default (drawn from
-32 chunks per wave on)."""
+128 chunks per wave on)."""
 import numpy as np
 import pytest
 
@@ -58,9 +58,9 @@ def test_drawn_runs_equal_fixed_shares_bit_for_bit(env, oracle):
             assert scaled_err(drawn[0].cpu().numpy(), ref) <= 1e-12   # (the last round ran without history)
 
 
-@pytest.mark.parametrize("nchan,log2n,nt", [(256, 20, 255), (1, 27, 101), (8, 24, 63), (2048, 17, 128)])
+@pytest.mark.parametrize("nchan,log2n,nt", [(256, 20, 255), (1, 28, 101), (8, 25, 63), (2048, 17, 128)])
 def test_default_draw_on_large_inputs(env, nchan, log2n, nt):
-    """Inputs large enough for the default to draw (32 chunks per wave or more): three launches in a row against the
+    """Inputs large enough for the default to draw (128 chunks per wave or more): three launches in a row against the
     fixed shares, bit for bit -- long runs, the short runs of the last quarter, one counter or eight."""
     dsp, torch, hook = env
     n = 1 << log2n
