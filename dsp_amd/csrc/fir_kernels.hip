@@ -1259,13 +1259,14 @@ __global__ __launch_bounds__(kBlock, RESIDENT) void fir_f64_mfma4w_kernel(const 
 // its own).  While the products of one window run, the samples and taps of the next -- the next chunk's first
 // window after a chunk's last -- are in flight into registers; between two windows lies one LDS round trip.  Same
 // products in the same order as fir_f64_mfma4_kernel: same bits.
-// Large inputs with filters of up to 3072 taps, and wavelet banks, give that order up for another gain: the XCDs of a
-// chip hold clocks a few per cent apart, so with equal shares the launch ends with the slowest.  There a wave's chunks
-// after its first two are drawn from the counters of the launch's stream (FirRuns::tickets), a whole chunk before
-// they are needed; neighbouring chunks then land on any XCD and their overlapping reads miss its L2 (measured as L2
-// fetches from the fabric, which the infinity cache or HBM serves: 1023 taps 2 x the algorithmic read bytes for
-// +1.2 % of throughput; the 65-scale bank 3.6 GB instead of 0.4 GB per launch for +1.4 %).  Longer filters run at
-// the chip's full clock on every XCD and keep the fixed order.
+// Large inputs with filters of up to 3072 taps, and wavelet banks, keep that order for the first seven eighths of
+// every channel (row) only: the XCDs of a chip hold clocks a few per cent apart, so with equal shares the launch ends
+// with the slowest.  The last eighth of every channel is a pool from which the waves draw chunk by chunk through the
+// counters of the launch's stream (FirRuns::tickets), a whole chunk before they need it; the XCDs that are through
+// with their stretches first take more of it.  The pool's chunks land on any XCD and their overlapping reads miss its
+// L2 (measured as L2 fetches from the fabric: 1023 taps 1.12 x the algorithmic read bytes instead of 1.01 x, for
+// +1.4 % of throughput; with every chunk drawn 2.0 x for +1.2 %).  Longer filters run at the chip's full clock on
+// every XCD and keep the fixed order throughout.
 //
 // BANK (the wavelet path, reference dsp.hpp:1136-1217): one input, rows of taps of different lengths.  A unit of work is
 // a chunk of one row: 1024 values of c[t] = sum_k taps_r[k] * x[t + advance_r - k] (zeros outside [0, n)), of which the
@@ -1438,25 +1439,27 @@ __global__ __launch_bounds__(kBlock, RESIDENT) void fir_f64_mfma4wm_kernel(const
     // The last stretch is usually a partial one: its runs are dealt round-robin over the XCDs instead, so that what is
     // left (all there is, for a small input) is spread over the whole chip and not over the first XCDs only.
     const unsigned per_stretch = 8 * per_xcd;
+    const unsigned lead = rn.tickets != nullptr ? rn.lead_runs : rn.total_runs;   // the runs dealt in stretches (all, without a pool)
     auto run_at = [&](unsigned first, unsigned pl) __attribute__((always_inline)) {
-        return first + per_stretch > rn.total_runs ? first + in_xcd * 8 + xcd : first + xcd * per_xcd + pl;
+        return first + per_stretch > lead ? first + in_xcd * 8 + xcd : first + xcd * per_xcd + pl;
     };
     unsigned stretch = 0, place = in_xcd;  // `stretch`: the first run of the stretch the wave is in
-    unsigned run = run_at(stretch, place);
-    // Drawn chunks (rn.tickets, as in fir_f64_mfma4w_kernel: counter groups made of workgroups of every XCD): the wave's
-    // first two chunks are fixed, every later one is drawn from its group's counter a whole chunk before it is needed
-    // (the chunk after the current one must be known when the current one's last window starts).
+    unsigned run = run_at(stretch, place);   // (with a pool: every wave has one, the launcher sees to that)
+    // Drawn chunks (rn.tickets; counter groups made of workgroups of every XCD, as in fir_f64_mfma4w_kernel).  The first
+    // seven eighths of every channel (row) -- runs [0, lead), in the run order of run_span() -- are dealt in stretches,
+    // XCD by XCD, as above; the last eighth of every channel is a pool: a wave's first two pool chunks are fixed, every
+    // later one is drawn from its group's counter a whole chunk before it is needed (the chunk after the current one
+    // must be known when the current one's last window starts).  The XCDs that are through with their stretches first
+    // take more of the pool, so the launch does not end with the slowest XCD, and only the pool's chunks lose the
+    // XCD-by-XCD order that keeps overlapping reads in an XCD's L2.
     const unsigned decks = rn.decks;
     const unsigned deck = (blockIdx.x >> 3) & (decks - 1);
     unsigned* const tickets = rn.tickets != nullptr ? rn.tickets + deck * kTicketStride : nullptr;
     const unsigned deck_blocks = gridDim.x / decks, deck_waves = deck_blocks * (kBlock / 64);
     const unsigned deck_wave = (((blockIdx.x >> 3) / decks) * 8 + (blockIdx.x & 7)) * (kBlock / 64) + wave;
+    const unsigned pool_first = lead + decks * deck_wave + deck, pool_second = lead + decks * (deck_waves + deck_wave) + deck;
+    bool pooled = false;   // the chunk in hand comes from the pool
     unsigned known_next = 0, drawn = 0;
-    if (tickets != nullptr) {
-        run = decks * deck_wave + deck;
-        known_next = decks * (deck_waves + deck_wave) + deck;
-        if (lane == 0) drawn = __hip_atomic_fetch_add(tickets, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
     if (run < rn.total_runs) {
         // The chunk in hand: its channel (row), `pos` = the sample position of its first value, `yk` / `opos` = where its
         // first output goes and which output of the channel that is.
@@ -1466,9 +1469,9 @@ __global__ __launch_bounds__(kBlock, RESIDENT) void fir_f64_mfma4wm_kernel(const
         unsigned left_in_run;   // chunks of the run after the current one
         auto locate = [&](unsigned r, Filter& f, const double*& cx, const double*& ch, double*& cy, long long& cpos,
                           long long& copos, unsigned& more) __attribute__((always_inline)) {
-            const unsigned chan = (unsigned)(((unsigned long long)r * rn.div_magic) >> rn.div_shift);
-            const unsigned c0 = (r - chan * rn.runs_per_chan) * rn.run_chunks;
-            more = min(c0 + rn.run_chunks, rn.chunks_per_chan) - c0 - 1;
+            const RunSpan span = run_span(rn, r);
+            const unsigned chan = span.chan, c0 = span.c0;
+            more = span.c1 - c0 - 1;
             copos = (long long)c0 * kOutputs;
             if constexpr (BANK) {
                 const BankRow row = bank[chan];
@@ -1494,7 +1497,8 @@ __global__ __launch_bounds__(kBlock, RESIDENT) void fir_f64_mfma4wm_kernel(const
             const bool last_window = e0 + steps >= cur.total_steps;
             // the window after this one: the chunk's next, the first of the run's next chunk, or of the wave's next run
             const unsigned next_place = place + 1 == per_xcd ? 0 : place + 1;
-            const unsigned next_run = tickets != nullptr ? known_next : run_at(stretch + per_stretch, next_place);
+            const unsigned stretch_next = run_at(stretch + per_stretch, next_place);   // (past `lead`: none)
+            const unsigned next_run = tickets == nullptr ? stretch_next : pooled ? known_next : stretch_next < lead ? stretch_next : pool_first;
             const bool have_next = !last_window || left_in_run > 0 || next_run < rn.total_runs;
             const double *n_xc = xc, *n_hc = hc;
             double* n_yk = yk;
@@ -1605,10 +1609,16 @@ __global__ __launch_bounds__(kBlock, RESIDENT) void fir_f64_mfma4wm_kernel(const
                 pend_left = negative(left - kOutputs) ? (int)left : kOutputs;
                 stores_due = true;
                 if (left_in_run == 0) {
-                    run = next_run, stretch += per_stretch, place = next_place;
-                    if (tickets != nullptr && have_next) {
-                        known_next = decks * (2 * deck_waves + (unsigned)__builtin_amdgcn_readfirstlane((int)drawn)) + deck;
-                        if (known_next < rn.total_runs && lane == 0)   // (a wave stops drawing at its first number past the end)
+                    run = next_run;
+                    if (tickets == nullptr || (!pooled && stretch_next < lead)) {
+                        stretch += per_stretch, place = next_place;
+                    } else if (have_next) {
+                        // into the pool, or on within it: the chunk after the next becomes known, the one after that is drawn
+                        // (a draw is only made while the known chunk lies inside the input, and only read when one was made)
+                        known_next = !pooled ? pool_second
+                                             : lead + decks * (2 * deck_waves + (unsigned)__builtin_amdgcn_readfirstlane((int)drawn)) + deck;
+                        pooled = true;
+                        if (known_next < rn.total_runs && lane == 0)
                             drawn = __hip_atomic_fetch_add(tickets, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
                 }
@@ -1884,14 +1894,29 @@ void forget_stream(hipStream_t stream) {
 // group.  `ntaps`: the (mean) filter length, for the estimate of the launch's duration.
 static void draw_chunks(FirRuns& rn, unsigned& wgs, unsigned nchan, long long n, double ntaps, unsigned* tickets) {
     constexpr unsigned kWaves = kBlock / 64;
-    if (tickets == nullptr || wgs < 8 || rn.total_runs < 4ull * wgs * kWaves) return;   // (two fixed runs per wave, then at least as many drawn)
+    if (tickets == nullptr || wgs < 8 || rn.run_chunks != 1) return;
+    // The last eighth of every channel's chunks is the pool the waves draw from; what comes before is dealt in
+    // stretches of one chunk per wave, XCD by XCD.  Worth it from four pool chunks per wave (two of them are fixed)
+    // and one stretch before them.
+    const unsigned cpc = rn.chunks_per_chan, lead_chunks = (unsigned)((unsigned long long)cpc * 7 / 8), tail_chunks = cpc - lead_chunks;
     const double outputs = (double)n * nchan;
     const double micros = std::max(outputs * 2.0 * ntaps / 60e6, outputs * 16.0 / 5e6);
-    rn.decks = 1;
-    while (rn.decks < kMaxRunDecks && rn.total_runs > 10.0 * micros * rn.decks) rn.decks *= 2;
-    while (rn.decks > 1 && wgs < 8 * rn.decks) rn.decks /= 2;
-    wgs = std::max(wgs / (8 * rn.decks) * (8 * rn.decks), 8u);
+    const unsigned long long pool = (unsigned long long)nchan * tail_chunks, lead = (unsigned long long)nchan * lead_chunks;
+    unsigned decks = 1;
+    while (decks < kMaxRunDecks && pool > 10.0 * (micros / 8) * decks) decks *= 2;   // (the pool's draws fall into the launch's last eighth)
+    while (decks > 1 && wgs < 8 * decks) decks /= 2;
+    const unsigned grid = std::max(wgs / (8 * decks) * (8 * decks), 8u), waves = grid * kWaves;
+    if (lead_chunks == 0 || tail_chunks == 0 || lead < waves || pool < 4ull * waves) return;
+    wgs = grid;
+    rn.decks = decks;
     rn.tickets = tickets;
+    rn.runs_per_chan = lead_chunks, rn.lead_chunks = lead_chunks, rn.lead_runs = (unsigned)lead;
+    rn.tail_chan0 = 0, rn.tail_c0 = lead_chunks, rn.tail_runs_per_chan = tail_chunks, rn.tail_run_chunks = 1;
+    FirShape d{};
+    set_divider(d, lead_chunks);
+    rn.div_magic = d.div_magic, rn.div_shift = d.div_shift;
+    set_divider(d, tail_chunks);
+    rn.tail_div_magic = d.div_magic, rn.tail_div_shift = d.div_shift;
 }
 
 // The several-windows kernel as the wavelet bank runs it: 1024-value chunks, 576 halo slots (143 steps per window).
@@ -1939,10 +1964,8 @@ static void launch_mfma_variant(const double* taps, const double* x, const doubl
             const unsigned max_waves = compute_units() * ((big || several) ? 2u : 4u) * kWaves;
             FirRuns rn;
             const unsigned nchan = shape.total_tiles / shape.tiles_per_chan, chunk = (big || several) ? 1024 : 512;
-            // The several-windows kernel draws its chunks only for filters of up to kDrawnChunkTaps taps: beyond, the chip
-            // sits at its full clock on every XCD and there is nothing to balance, while chunks that are no longer dealt
-            // XCD by XCD cost HBM reads (4095 taps: 4.1 x the algorithmic bytes instead of 1.04 x; 1023 taps: 2.0 x
-            // instead of 1.03 x, for +1.2 % of throughput -- runs of two or four chunks per draw read no less).
+            // The several-windows kernel has a pool of drawn chunks only for filters of up to kDrawnChunkTaps taps: beyond,
+            // the chip sits at its full clock on every XCD and there is nothing to balance.
             constexpr int kDrawnChunkTaps = 3072;
             const bool may_draw = large_enough_to_draw(nchan, shape.n, max_waves, chunk, several ? kDrawnChunksFrom : kDrawnFrom) &&
                                   (!several || shape.ntaps <= kDrawnChunkTaps);
@@ -2098,7 +2121,9 @@ hipError_t launch_checksum(const double* yv, unsigned long long n, unsigned long
 // size (by default only inputs of 128 chunks per wave or more do); 0 restores the default.  Returns the previous
 // setting.  dspx_test_forget_stream: gives an idle stream's counters back (what the library does for its own
 // streams before it destroys them).  dspx_test_run_plan: the runs plan_runs() cuts an input into, decoded as the kernels decode them
-// (chan, first chunk, end chunk per run); returns the number of runs, or -1 when the plan does not fit `cap`.
+// (chan, first chunk, end chunk per run; `drawn` 0: fixed shares, 1: drawn runs, 2: the several-windows kernel's
+// stretches and pool; *lead_runs = the runs before the short runs / before the pool); returns the number of runs, or
+// -1 when the plan does not fit `cap`.
 extern "C" __attribute__((visibility("default"))) int dspx_test_run_shares(int mode) {
     return dspx::g_share_mode.exchange(mode);
 }
@@ -2110,7 +2135,13 @@ extern "C" __attribute__((visibility("default"))) long long dspx_test_run_plan(u
                                                                             size_t cap, unsigned* lead_runs) {
     dspx::FirRuns rn;
     unsigned dummy[1];
-    if (!dspx::plan_runs(nchan, n, max_waves, rn, chunk, 0, drawn ? dummy : nullptr)) return -1;
+    if (drawn == 2) {   // the several-windows kernel's plan: runs of one chunk, the last eighth of every channel a pool
+        if (!dspx::plan_runs(nchan, n, max_waves, rn, chunk, 1, nullptr)) return -1;
+        unsigned wgs = max_waves / 4;
+        dspx::draw_chunks(rn, wgs, nchan, n, 1000.0, dummy);
+    } else if (!dspx::plan_runs(nchan, n, max_waves, rn, chunk, 0, drawn ? dummy : nullptr)) {
+        return -1;
+    }
     if (rn.total_runs > cap) return -1;
     for (unsigned r = 0; r < rn.total_runs; ++r) {
         const dspx::RunSpan sp = dspx::run_span(rn, r);

@@ -67,3 +67,19 @@ def test_fixed_shares_are_the_default_plan_for_small_inputs():
         a, _ = _plan(nchan, n, 4096, 512, 0)
         b, lead = _plan(nchan, n, 4096, 512, 1)
         assert np.array_equal(a, b) and lead == len(b)
+
+
+def test_chunk_pool_of_the_several_windows_kernel():
+    """The several-windows kernel (runs of one chunk): the first seven eighths of every channel are dealt in stretches,
+    the last eighth of every channel is the pool the waves draw from.  Every chunk exactly once; small inputs keep
+    the plain plan."""
+    for nchan, n, chunk, waves in [(62, 1 << 22, 1022, 2048), (2048, 1 << 20, 1024, 2048), (1, 1 << 26, 1024, 2048),
+                                   (3, 99_999_999, 1024, 2048), (512, 1 << 20, 1024, 2048)]:
+        spans, lead = _check(nchan, n, waves, chunk, 2)
+        cpc = -(-n // chunk)
+        assert np.all(spans[:, 2] - spans[:, 1] == 1)
+        assert lead == nchan * (cpc * 7 // 8)
+        assert np.all(spans[:lead, 1] < cpc * 7 // 8) and np.all(spans[lead:, 1] >= cpc * 7 // 8)
+    for nchan, n in [(4, 1 << 20), (1, 1 << 22), (3, 9_999_999)]:   # fewer than four pool chunks per wave: no pool
+        spans, lead = _check(nchan, n, 2048, 1024, 2)
+        assert lead == len(spans)
