@@ -803,8 +803,13 @@ __global__ __launch_bounds__(kBlock, OB == 4 ? 2 : 4) void fir_f64_mfma4_kernel(
 // Per chunk a wave issues, besides its matrix instructions, 4 (8) loads, 8 (16) stores, about 30 (45) LDS instructions
 // and about two dozen vector instructions, and waits for nobody but itself: between the last matrix instruction of a
 // chunk and the first of the next lies one LDS round trip.  The 1024-output chunks halve the LDS reads per matrix
-// instruction and the hand-overs per output at the price of two resident workgroups per CU instead of four; they win
-// from 190 taps on.
+// instruction and the hand-overs per output at the price of two or three resident workgroups per CU instead of four
+// or five; they win from 190 taps on.
+// Everything a wave loads ahead of its use (the next chunk's samples, the halo's tail, a next run's first window) is
+// loaded by all of its lanes -- a lane past the end of the range takes the range's last element -- and only the stores
+// that follow stand under a lane condition: registers that a load defines on some lanes' paths only are copied around
+// by the compiler, chunk after chunk, on the vector unit, whose cycles are the matrix instructions' own (measured: 69
+// vector instructions per chunk before, 28 after; 128 -> 89 registers per lane for the 512-output chunks).
 //
 // What bounds it (timestamps inside the kernel, tools/m4w_timing.py; builds with the loads or the stores left out):
 // the product loop's marginal cost is exactly its matrix-pipe time, the pipe is occupied 87 % (101 taps) to 95 %
@@ -888,8 +893,8 @@ __device__ __forceinline__ unsigned long long stamp() {
 
 // OB: a segment is 16 * OB consecutive outputs (4 * OB row blocks, one accumulator each), a chunk 16 segments.
 // HG: pad groups (of one segment's length) in front of the samples of a chunk.  <HG 9, OB 2>: 512-output chunks, 288
-// halo slots, four workgroups per CU (128 VGPRs); <5, 4> and <9, 4>: 1024-output chunks, 320 / 576 halo slots (up to
-// 313 / 569 taps), two workgroups per CU (192 / 208 VGPRs).
+// halo slots, four workgroups per CU, five from 90 taps (89 VGPRs); <5, 4> and <9, 4>: 1024-output chunks, 320 / 576
+// halo slots (up to 313 / 569 taps), three / two workgroups per CU (148 / 158 VGPRs; LDS holds no third with 576 slots).
 template <int RESIDENT, int HG, int OB>
 __global__ __launch_bounds__(kBlock, RESIDENT) void fir_f64_mfma4w_kernel(const double* __restrict__ taps,
                                                                            const double* __restrict__ x,
@@ -952,8 +957,15 @@ __global__ __launch_bounds__(kBlock, RESIDENT) void fir_f64_mfma4w_kernel(const 
     double* o_home = imgd + kHaloGroups * G::kPadStep + G::kOutStep * (lane & 15) + (lane >> 4);   // acc[rb] -> o_home[4 * rb]
     const double* g_home = imgd + kHaloGroups * G::kPadStep + lane + (lane >> G::kShift);           // output lane + 64 j at g_home[66 j]
     constexpr int kBackStep = 64 + 64 / G::kSeg;
-    const dvec2* t_src = imgw + (kImgGroups - hgroups) * kGroupPairs + lane;      // halo carry: pair lane + 64 i
-    dvec2* t_dst = imgw + (kHaloGroups - hgroups) * kGroupPairs + lane;
+    // halo carry: pair lane + 64 i of the image's tail goes to the same pair of the halo's place.  A lane past the tail's
+    // end reads the tail's last pair instead and writes nothing.  A load that every lane executes defines its registers
+    // on every path: the compiler then needs no copies of them around it (loads under a lane condition cost some forty
+    // moves per chunk, on the unit the products use); the condition is on the stores, which define nothing.
+    int t_off[kHaloIters];
+#pragma unroll
+    for (int i = 0; i < kHaloIters; ++i) t_off[i] = lane + 64 * i < hpairs ? lane + 64 * i : hpairs - 1;
+    dvec2* const t_dst = imgw + (kHaloGroups - hgroups) * kGroupPairs + lane;
+    const dvec2* const t_base = imgw + (kImgGroups - hgroups) * kGroupPairs;
     dvec2* b_dst = imgw + kHaloGroups * kGroupPairs + lane + (lane >> kPG);       // body pair lane + 64 i at b_dst[i * kPairStep]
     dvec2* f_dst = imgw + (qlo / G::kSeg) * kGroupPairs + lane + (lane >> kPG);   // first window: pair lane + 64 i from qlo
     constexpr int kPairStep = 64 + 128 / G::kSeg;   // image distance of pairs 64 apart (one pad pair per group)
@@ -992,6 +1004,12 @@ __global__ __launch_bounds__(kBlock, RESIDENT) void fir_f64_mfma4w_kernel(const 
     const int npairs = (kHalo + kChunk - qlo) / 2;   // sample pairs of a run's first window
     static_assert(kBodyIters + kHaloIters >= kFirstIters, "a first window fits in the registers of a body and a halo");
     bool window_ready = false;   // the image holds the run's first window already (fetched during the run before)
+    // The pair of a first window that this lane fetches in its i-th load: lane + 64 i, the window's last pair for the
+    // lanes past its end (as for the halo carry).  Formed where it is used, not carried through the products.
+    auto window_pair = [&](int i) __attribute__((always_inline)) {
+        const int p = fresh(lane) + 64 * i;
+        return p < npairs ? p : npairs - 1;
+    };
     for (unsigned run = tickets != nullptr ? decks * (deck_place * (kBlock / 64) + wave) + deck
                                            : blockIdx.x * (kBlock / 64) + wave;
          run < rn.total_runs;) {
@@ -1009,8 +1027,7 @@ __global__ __launch_bounds__(kBlock, RESIDENT) void fir_f64_mfma4w_kernel(const 
                 const dvec2* src = reinterpret_cast<const dvec2*>(xc + g_lo);
                 dvec2 F[kFirstIters];
 #pragma unroll
-                for (int i = 0; i < kFirstIters; ++i)
-                    if (lane + 64 * i < npairs) F[i] = scalar_base(src + 64 * i)[(unsigned)lane];
+                for (int i = 0; i < kFirstIters; ++i) F[i] = scalar_base(src)[(unsigned)window_pair(i)];
 #pragma unroll
                 for (int i = 0; i < kFirstIters; ++i)
                     if (lane + 64 * i < npairs) f_dst[i * kPairStep] = F[i];
@@ -1055,6 +1072,7 @@ __global__ __launch_bounds__(kBlock, RESIDENT) void fir_f64_mfma4w_kernel(const 
                     for (int i = 0; i < kBodyIters; ++i) asm volatile("" : "=v"(R[i]));
                 }
             } else {
+                asm volatile("" ::"v"(drawn));   // (the drawn number is waited for here on every path, as the samples below)
                 next_run = tickets != nullptr ? decks * (deck_waves + (unsigned)__builtin_amdgcn_readfirstlane((int)drawn)) + deck
                                               : run + nwaves;
                 if (next_run < rn.total_runs) {
@@ -1064,8 +1082,7 @@ __global__ __launch_bounds__(kBlock, RESIDENT) void fir_f64_mfma4w_kernel(const 
                         switch_run = true;
                         const dvec2* src = reinterpret_cast<const dvec2*>(x + (unsigned long long)ns.chan * s.x_stride + ng_lo);
 #pragma unroll
-                        for (int i = 0; i < kFirstIters; ++i)
-                            if (lane + 64 * i < npairs) F[i] = scalar_base(src + 64 * i)[(unsigned)lane];
+                        for (int i = 0; i < kFirstIters; ++i) F[i] = scalar_base(src)[(unsigned)window_pair(i)];
                     }
                 }
             }
@@ -1082,8 +1099,7 @@ __global__ __launch_bounds__(kBlock, RESIDENT) void fir_f64_mfma4w_kernel(const 
             dvec2 Tl[have_next ? kHaloIters : 1];
             if constexpr (have_next) {
 #pragma unroll
-                for (int i = 0; i < kHaloIters; ++i)
-                    if (lane + 64 * i < hpairs) Tl[i] = t_src[64 * i];
+                for (int i = 0; i < kHaloIters; ++i) Tl[i] = t_base[t_off[i]];
             }
             if (stores_due && !(M4W_ABLATE & 2)) store_chunk();
             if ((M4W_ABLATE & 2) && stores_due) {
@@ -1190,6 +1206,17 @@ __global__ __launch_bounds__(kBlock, RESIDENT) void fir_f64_mfma4w_kernel(const 
 #pragma unroll
             for (int j = 0; j < kStores; ++j) O[j] = g_home[j * kBackStep];
             wave_fence();
+            // The prefetched samples are waited for here on every path, also on those that will not use them: the
+            // compiler cannot tell that a path which skipped the loads skips their use too, and would otherwise wait
+            // for "loads still in flight" where the registers are written next -- at the top of a chunk, behind that
+            // chunk's own prefetch.
+            if constexpr (have_next) {
+#pragma unroll
+                for (int i = 0; i < kBodyIters; ++i) asm volatile("" ::"v"(R[i]));
+            } else {
+#pragma unroll
+                for (int i = 0; i < kFirstIters; ++i) asm volatile("" ::"v"(F[i]));
+            }
             if constexpr (have_next) {
                 if (next_full) {
 #pragma unroll
@@ -1768,9 +1795,9 @@ static std::atomic<int> g_share_mode{0};   // test hook (dspx_test_run_shares): 
 // channel when there are few channels, the first three quarters of the channels otherwise --, about kLeadPerWave per
 // wave, then runs an eighth as long over the rest.
 // (Measured: at 64 chunks per wave -- launches of half a millisecond to a millisecond -- drawn runs are 1-4 % slower than
-// fixed shares, because the long runs a wave commits to when it starts are most of its work; at 128 they are equal
-// or faster.)
-constexpr unsigned long long kDrawnFrom = 128;
+// fixed shares, because the long runs a wave commits to when it starts are most of its work; at 100 and more they are
+// equal or faster.)
+constexpr unsigned long long kDrawnFrom = 100;
 // The several-windows kernel draws single chunks from a wave's third chunk on, so it adapts from the start: it draws
 // from kDrawnChunksFrom chunks per wave.
 constexpr unsigned long long kDrawnChunksFrom = 32;
@@ -1952,8 +1979,8 @@ static void launch_mfma_variant(const double* taps, const double* x, const doubl
     if constexpr (!BANK) {
         if (vec2 && !tiled && shape.ntaps > 0) {
             // The wave-autonomous forms (measured on one box, tools/tap_sweep.py): up to 189 taps 512-output chunks with
-            // a 288-slot halo, four workgroups per CU; up to 569 taps 1024-output chunks (half the LDS reads per matrix
-            // instruction, half the chunk hand-overs) with a 320- or 576-slot halo, two workgroups per CU; beyond that
+            // a 288-slot halo, four or five workgroups per CU; up to 569 taps 1024-output chunks (half the LDS reads per matrix
+            // instruction, half the chunk hand-overs) with a 320- or 576-slot halo, three or two workgroups per CU; beyond that
             // several windows per 1024-output chunk, each with a 576-slot halo (143 steps; 512-output chunks with
             // windows of 71 steps measured 1-2 % slower from 570 to 4095 taps).
             constexpr unsigned kWaves = kBlock / 64;
@@ -1961,7 +1988,13 @@ static void launch_mfma_variant(const double* taps, const double* x, const doubl
             const int steps = (shape.ntaps + 2) / 4 + 1;
             const bool big = steps >= kBigFrom && steps <= 2 * M4Geo<2>::kStageSteps + 1;
             const bool several = steps > 2 * M4Geo<2>::kStageSteps + 1;   // several windows per chunk: runs of one chunk
-            const unsigned max_waves = compute_units() * ((big || several) ? 2u : 4u) * kWaves;
+            // Workgroups per CU: the 512-output chunks four, from 90 taps five (89 registers per lane; measured +0.4...0.9 %
+            // from 96 to 160 taps, -1 % at 63); the 1024-output chunks three where the halo has 320 slots (up to 313
+            // taps: +1 % over two), else two, as many as a CU's LDS holds.
+            constexpr int kFiveFrom = 24;
+            const bool mid = big && steps <= M4Geo<4>::kStageSteps;
+            const bool five = !big && !several && steps >= kFiveFrom;
+            const unsigned max_waves = compute_units() * (mid ? 3u : (big || several) ? 2u : five ? 5u : 4u) * kWaves;
             FirRuns rn;
             const unsigned nchan = shape.total_tiles / shape.tiles_per_chan, chunk = (big || several) ? 1024 : 512;
             // The several-windows kernel has a pool of drawn chunks only for filters of up to kDrawnChunkTaps taps: beyond,
@@ -1985,10 +2018,12 @@ static void launch_mfma_variant(const double* taps, const double* x, const doubl
                     wgs = std::max(wgs / (8 * rn.decks) * (8 * rn.decks), 8u);   // (groups of equal size)
                 }
                 const dim3 wgrid(wgs);
-                if (steps < kBigFrom)
+                if (five)
+                    hipLaunchKernelGGL((fir_f64_mfma4w_kernel<5, 9, 2>), wgrid, block, 0, stream, taps, x, hist, y, shape, rn);
+                else if (steps < kBigFrom)
                     hipLaunchKernelGGL((fir_f64_mfma4w_kernel<4, 9, 2>), wgrid, block, 0, stream, taps, x, hist, y, shape, rn);
                 else if (steps <= M4Geo<4>::kStageSteps)
-                    hipLaunchKernelGGL((fir_f64_mfma4w_kernel<2, 5, 4>), wgrid, block, 0, stream, taps, x, hist, y, shape, rn);
+                    hipLaunchKernelGGL((fir_f64_mfma4w_kernel<3, 5, 4>), wgrid, block, 0, stream, taps, x, hist, y, shape, rn);
                 else if (big)
                     hipLaunchKernelGGL((fir_f64_mfma4w_kernel<2, 9, 4>), wgrid, block, 0, stream, taps, x, hist, y, shape, rn);
                 else

@@ -62,7 +62,7 @@ def test_drawn_runs_end_with_short_runs():
 
 
 def test_fixed_shares_are_the_default_plan_for_small_inputs():
-    """Inputs of fewer than 128 chunks per wave keep the fixed shares even when a counter is available."""
+    """Inputs of fewer than 100 chunks per wave keep the fixed shares even when a counter is available."""
     for nchan, n in [(16, 1 << 20), (1, 1 << 24), (4096, 1000), (1, 1 << 27), (64, 1 << 21)]:
         a, _ = _plan(nchan, n, 4096, 512, 0)
         b, lead = _plan(nchan, n, 4096, 512, 1)
