@@ -803,8 +803,8 @@ __global__ __launch_bounds__(kBlock, OB == 4 ? 2 : 4) void fir_f64_mfma4_kernel(
 // Per chunk a wave issues, besides its matrix instructions, 4 (8) loads, 8 (16) stores, about 30 (45) LDS instructions
 // and about two dozen vector instructions, and waits for nobody but itself: between the last matrix instruction of a
 // chunk and the first of the next lies one LDS round trip.  The 1024-output chunks halve the LDS reads per matrix
-// instruction and the hand-overs per output at the price of two or three resident workgroups per CU instead of four
-// or five; they win from 190 taps on.
+// instruction and the hand-overs per output at the price of two or three resident workgroups per CU instead of four;
+// they win from 78 taps on.
 // Everything a wave loads ahead of its use (the next chunk's samples, the halo's tail, a next run's first window) is
 // loaded by all of its lanes -- a lane past the end of the range takes the range's last element -- and only the stores
 // that follow stand under a lane condition: registers that a load defines on some lanes' paths only are copied around
@@ -893,8 +893,8 @@ __device__ __forceinline__ unsigned long long stamp() {
 
 // OB: a segment is 16 * OB consecutive outputs (4 * OB row blocks, one accumulator each), a chunk 16 segments.
 // HG: pad groups (of one segment's length) in front of the samples of a chunk.  <HG 9, OB 2>: 512-output chunks, 288
-// halo slots, four workgroups per CU, five from 90 taps (89 VGPRs); <5, 4> and <9, 4>: 1024-output chunks, 320 / 576
-// halo slots (up to 313 / 569 taps), three / two workgroups per CU (148 / 158 VGPRs; LDS holds no third with 576 slots).
+// halo slots, four workgroups per CU (89 VGPRs; up to 77 taps); <5, 4> and <9, 4>: 1024-output chunks, 320 / 576 halo
+// slots (up to 313 / 569 taps), three / two workgroups per CU (148 / 158 VGPRs; LDS holds no third with 576 slots).
 template <int RESIDENT, int HG, int OB>
 __global__ __launch_bounds__(kBlock, RESIDENT) void fir_f64_mfma4w_kernel(const double* __restrict__ taps,
                                                                            const double* __restrict__ x,
@@ -1797,7 +1797,7 @@ static std::atomic<int> g_share_mode{0};   // test hook (dspx_test_run_shares): 
 // (Measured: at 64 chunks per wave -- launches of half a millisecond to a millisecond -- drawn runs are 1-4 % slower than
 // fixed shares, because the long runs a wave commits to when it starts are most of its work; at 100 and more they are
 // equal or faster.)
-constexpr unsigned long long kDrawnFrom = 100;
+constexpr unsigned long long kDrawnFrom = 100, kDrawnFromBig = 80;   // (chunks of 512 / of 1024 outputs)
 // The several-windows kernel draws single chunks from a wave's third chunk on, so it adapts from the start: it draws
 // from kDrawnChunksFrom chunks per wave.
 constexpr unsigned long long kDrawnChunksFrom = 32;
@@ -1978,29 +1978,29 @@ static void launch_mfma_variant(const double* taps, const double* x, const doubl
     }
     if constexpr (!BANK) {
         if (vec2 && !tiled && shape.ntaps > 0) {
-            // The wave-autonomous forms (measured on one box, tools/tap_sweep.py): up to 189 taps 512-output chunks with
-            // a 288-slot halo, four or five workgroups per CU; up to 569 taps 1024-output chunks (half the LDS reads per matrix
-            // instruction, half the chunk hand-overs) with a 320- or 576-slot halo, three or two workgroups per CU; beyond that
-            // several windows per 1024-output chunk, each with a 576-slot halo (143 steps; 512-output chunks with
-            // windows of 71 steps measured 1-2 % slower from 570 to 4095 taps).
+            // The wave-autonomous forms (measured on one box, tools/tap_sweep.py and same-box A/B): up to 77 taps 512-output
+            // chunks with a 288-slot halo, four workgroups per CU; up to 569 taps 1024-output chunks (half the LDS reads
+            // per matrix instruction, half the chunk hand-overs) with a 320- or 576-slot halo, three or two workgroups per
+            // CU; beyond that several windows per 1024-output chunk, each with a 576-slot halo (143 steps; 512-output
+            // chunks with windows of 71 steps measured 1-2 % slower from 570 to 4095 taps).
             constexpr unsigned kWaves = kBlock / 64;
-            constexpr int kBigFrom = 49;   // steps of four tap offsets from which the 1024-output chunks win (190 taps)
+            // Steps of four tap offsets from which the 1024-output chunks win: 78 taps, with three workgroups per CU
+            // (+0.4...1.5 % from 80 to 176 taps, +1 % on a single stream of 2^28 samples at 101 taps; -0.5 % at 63 taps,
+            // -5 % there on a single stream.  With two workgroups per CU they won from 190 taps only).
+            constexpr int kBigFrom = 21;
             const int steps = (shape.ntaps + 2) / 4 + 1;
             const bool big = steps >= kBigFrom && steps <= 2 * M4Geo<2>::kStageSteps + 1;
             const bool several = steps > 2 * M4Geo<2>::kStageSteps + 1;   // several windows per chunk: runs of one chunk
-            // Workgroups per CU: the 512-output chunks four, from 90 taps five (89 registers per lane; measured +0.4...0.9 %
-            // from 96 to 160 taps, -1 % at 63); the 1024-output chunks three where the halo has 320 slots (up to 313
-            // taps: +1 % over two), else two, as many as a CU's LDS holds.
-            constexpr int kFiveFrom = 24;
+            // Workgroups per CU: the 512-output chunks four (a fifth: -1 % at 63 taps); the 1024-output chunks three
+            // where the halo has 320 slots (up to 313 taps: +1 % over two), else two, as many as a CU's LDS holds.
             const bool mid = big && steps <= M4Geo<4>::kStageSteps;
-            const bool five = !big && !several && steps >= kFiveFrom;
-            const unsigned max_waves = compute_units() * (mid ? 3u : (big || several) ? 2u : five ? 5u : 4u) * kWaves;
+            const unsigned max_waves = compute_units() * (mid ? 3u : (big || several) ? 2u : 4u) * kWaves;
             FirRuns rn;
             const unsigned nchan = shape.total_tiles / shape.tiles_per_chan, chunk = (big || several) ? 1024 : 512;
             // The several-windows kernel has a pool of drawn chunks only for filters of up to kDrawnChunkTaps taps: beyond,
             // the chip sits at its full clock on every XCD and there is nothing to balance.
             constexpr int kDrawnChunkTaps = 3072;
-            const bool may_draw = large_enough_to_draw(nchan, shape.n, max_waves, chunk, several ? kDrawnChunksFrom : kDrawnFrom) &&
+            const bool may_draw = large_enough_to_draw(nchan, shape.n, max_waves, chunk, several ? kDrawnChunksFrom : big ? kDrawnFromBig : kDrawnFrom) &&
                                   (!several || shape.ntaps <= kDrawnChunkTaps);
             unsigned* const tickets = may_draw ? ticket_set(stream) : nullptr;
             if (plan_runs(nchan, shape.n, max_waves, rn, chunk, several ? 1 : 0, several ? nullptr : tickets)) {
@@ -2018,9 +2018,7 @@ static void launch_mfma_variant(const double* taps, const double* x, const doubl
                     wgs = std::max(wgs / (8 * rn.decks) * (8 * rn.decks), 8u);   // (groups of equal size)
                 }
                 const dim3 wgrid(wgs);
-                if (five)
-                    hipLaunchKernelGGL((fir_f64_mfma4w_kernel<5, 9, 2>), wgrid, block, 0, stream, taps, x, hist, y, shape, rn);
-                else if (steps < kBigFrom)
+                if (steps < kBigFrom)
                     hipLaunchKernelGGL((fir_f64_mfma4w_kernel<4, 9, 2>), wgrid, block, 0, stream, taps, x, hist, y, shape, rn);
                 else if (steps <= M4Geo<4>::kStageSteps)
                     hipLaunchKernelGGL((fir_f64_mfma4w_kernel<3, 5, 4>), wgrid, block, 0, stream, taps, x, hist, y, shape, rn);

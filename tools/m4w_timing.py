@@ -45,7 +45,7 @@ for nm in sys.argv[1:] or ["l101"]:
     se = (hwi >> 13) & 7
     xc = (t[:, 6].astype(np.int64) >> 32) & 15
     steps = (nt + 2) // 4 + 1
-    rb = 16 if 49 <= steps <= 143 else 8   # matrix instructions per step: 1024-output chunks from 190 to 569 taps
+    rb = 16 if 21 <= steps <= 143 else 8   # matrix instructions per step: 1024-output chunks from 78 to 569 taps
     print(f"== {nm}: {len(t)} waves, {nch.mean():.1f} chunks of {64 * rb} outputs per wave, {steps} steps = {steps * rb * 16} pipe cycles per chunk")
     print(f"   per chunk (mean over waves, s_memtime ticks): products {np.mean(prod / nch):8.0f}  probe {np.mean(probe / nch):7.0f}  "
           f"rest {np.mean(rest / nch):7.0f}   wave lifetime {np.mean(t1 - t0):.0f}, span {(t1.max() - t0.min()):.0f}")
