@@ -893,8 +893,9 @@ __device__ __forceinline__ unsigned long long stamp() {
 
 // OB: a segment is 16 * OB consecutive outputs (4 * OB row blocks, one accumulator each), a chunk 16 segments.
 // HG: pad groups (of one segment's length) in front of the samples of a chunk.  <HG 9, OB 2>: 512-output chunks, 288
-// halo slots, four workgroups per CU (89 VGPRs; up to 77 taps); <5, 4> and <9, 4>: 1024-output chunks, 320 / 576 halo
-// slots (up to 313 / 569 taps), three / two workgroups per CU (148 / 158 VGPRs; LDS holds no third with 576 slots).
+// halo slots, four workgroups per CU (89 VGPRs; up to 77 taps); <5, 4>, <7, 4> and <9, 4>: 1024-output chunks, 320 /
+// 448 / 576 halo slots (up to 313 / 441 / 569 taps), three / three / two workgroups per CU (148 / 154 / 158 VGPRs; LDS
+// holds no third with 576 slots).
 template <int RESIDENT, int HG, int OB>
 __global__ __launch_bounds__(kBlock, RESIDENT) void fir_f64_mfma4w_kernel(const double* __restrict__ taps,
                                                                            const double* __restrict__ x,
@@ -1980,8 +1981,8 @@ static void launch_mfma_variant(const double* taps, const double* x, const doubl
         if (vec2 && !tiled && shape.ntaps > 0) {
             // The wave-autonomous forms (measured on one box, tools/tap_sweep.py and same-box A/B): up to 77 taps 512-output
             // chunks with a 288-slot halo, four workgroups per CU; up to 569 taps 1024-output chunks (half the LDS reads
-            // per matrix instruction, half the chunk hand-overs) with a 320- or 576-slot halo, three or two workgroups per
-            // CU; beyond that several windows per 1024-output chunk, each with a 576-slot halo (143 steps; 512-output
+            // per matrix instruction, half the chunk hand-overs) with a 320-, 448- or 576-slot halo, three, three or two
+            // workgroups per CU; beyond that several windows per 1024-output chunk, each with a 576-slot halo (143 steps; 512-output
             // chunks with windows of 71 steps measured 1-2 % slower from 570 to 4095 taps).
             constexpr unsigned kWaves = kBlock / 64;
             // Steps of four tap offsets from which the 1024-output chunks win: 78 taps, with three workgroups per CU
@@ -1992,8 +1993,10 @@ static void launch_mfma_variant(const double* taps, const double* x, const doubl
             const bool big = steps >= kBigFrom && steps <= 2 * M4Geo<2>::kStageSteps + 1;
             const bool several = steps > 2 * M4Geo<2>::kStageSteps + 1;   // several windows per chunk: runs of one chunk
             // Workgroups per CU: the 512-output chunks four (a fifth: -1 % at 63 taps); the 1024-output chunks three
-            // where the halo has 320 slots (up to 313 taps: +1 % over two), else two, as many as a CU's LDS holds.
-            const bool mid = big && steps <= M4Geo<4>::kStageSteps;
+            // where the halo has 320 or 448 slots (up to 313 / 441 taps: +1 % over two), else two, as many as a CU's LDS
+            // holds.
+            constexpr int kMidSteps = 7 * M4Geo<4>::kSeg / 4 - 1;   // steps a 448-slot halo serves (111)
+            const bool mid = big && steps <= kMidSteps;
             const unsigned max_waves = compute_units() * (mid ? 3u : (big || several) ? 2u : 4u) * kWaves;
             FirRuns rn;
             const unsigned nchan = shape.total_tiles / shape.tiles_per_chan, chunk = (big || several) ? 1024 : 512;
@@ -2022,6 +2025,8 @@ static void launch_mfma_variant(const double* taps, const double* x, const doubl
                     hipLaunchKernelGGL((fir_f64_mfma4w_kernel<4, 9, 2>), wgrid, block, 0, stream, taps, x, hist, y, shape, rn);
                 else if (steps <= M4Geo<4>::kStageSteps)
                     hipLaunchKernelGGL((fir_f64_mfma4w_kernel<3, 5, 4>), wgrid, block, 0, stream, taps, x, hist, y, shape, rn);
+                else if (steps <= kMidSteps)
+                    hipLaunchKernelGGL((fir_f64_mfma4w_kernel<3, 7, 4>), wgrid, block, 0, stream, taps, x, hist, y, shape, rn);
                 else if (big)
                     hipLaunchKernelGGL((fir_f64_mfma4w_kernel<2, 9, 4>), wgrid, block, 0, stream, taps, x, hist, y, shape, rn);
                 else

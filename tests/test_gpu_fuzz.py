@@ -42,7 +42,7 @@ def test_fir_device_entry_fuzz(env, oracle):
     ns = [1, 2, 3, 7, 63, 255, 256, 257, 511, 512, 513, 1023, 1024, 1025, 2040, 2046, 2047, 2048, 2049, 4094, 4095, 4096,
           4097, 6000, 10000, 40001]
     taps_n = [1, 2, 3, 15, 16, 17, 31, 51, 52, 55, 56, 77, 78, 79, 95, 96, 97, 160, 189, 190, 223, 224, 225, 255, 256, 257, 271, 272, 273, 300,
-              313, 314, 515, 569, 570, 640, 1100, 2300]
+              313, 314, 441, 442, 515, 569, 570, 640, 1100, 2300]
     for case in range(240):
         nchan = int(rng.integers(1, 6))
         n = int(rng.choice(ns))

@@ -18,7 +18,7 @@ streams = [torch.cuda.Stream() for _ in range(6)]
 bad = 0
 pending = []   # (drawn result, fixed result, description), checked in batches so that launches overlap
 for case in range(cases):
-    nt = int(rng.choice([52, 57, 63, 77, 78, 101, 128, 189, 190, 255, 313, 314, 400, 569, 570, 700, 1023]))
+    nt = int(rng.choice([52, 57, 63, 77, 78, 101, 128, 189, 190, 255, 313, 314, 400, 441, 442, 569, 570, 700, 1023]))
     kind = rng.integers(4) if nt < 570 else 4
     if kind == 0:
         nchan, n = 1, int(rng.integers(1, 1 << 23))
